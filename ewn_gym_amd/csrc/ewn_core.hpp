@@ -1,0 +1,400 @@
+// ewn_core.hpp -- device-side game core for the gfx950 EWN engine.
+//
+// One game lives in a handful of registers: two 64-bit occupancy masks (bit c =
+// row*S+col), the cube positions packed 6 bits each, and one alive mask per side.
+// Nothing here follows the reference's numpy data structures (a signed int16 board
+// plus a masked structured cube_pos array, envs/ewn.py:49-58); the rules it has to
+// reproduce are cited per function.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned long long u64;
+typedef uint32_t u32;
+
+#define EWN_DEV __device__ __forceinline__
+
+// Board geometry, built on the host (ewn_capi.hip: make_geom) and passed by value
+// as a kernel argument, so every field is wave-uniform (SGPRs).
+struct Geom {
+    int S, L, CN, cells;
+    u64 not_lastcol, not_lastrow, not_firstcol, not_firstrow, corner_br;
+    u64 sq[8];          // sq[t] = cells with row >= t and col >= t  (distance to the bottom-right corner <= S-1-t)
+    int8_t init[64];    // initial board, envs/ewn.py:94-107
+};
+
+// SIDE 0 = TOP_LEFT (positive numbers), SIDE 1 = BOTTOM_RIGHT (negative numbers).
+template <int NW>
+struct GState {
+    u64 occP, occN;
+    u64 posP[NW], posN[NW]; // cube k (0-based) at bits [6*(k%10), +6) of word k/10
+    u32 aliveP, aliveN;
+};
+
+template <int NW>
+EWN_DEV int pos_get(const u64 (&w)[NW], int k)
+{
+    if constexpr (NW == 1) return (int)((w[0] >> (6 * k)) & 63ull);
+    else return k < 10 ? (int)((w[0] >> (6 * k)) & 63ull) : (int)((w[1] >> (6 * (k - 10))) & 63ull);
+}
+
+template <int NW>
+EWN_DEV void pos_set(u64 (&w)[NW], int k, int c)
+{
+    if constexpr (NW == 1) {
+        w[0] = (w[0] & ~(63ull << (6 * k))) | ((u64)c << (6 * k));
+    } else {
+        if (k < 10) w[0] = (w[0] & ~(63ull << (6 * k))) | ((u64)c << (6 * k));
+        else w[1] = (w[1] & ~(63ull << (6 * (k - 10)))) | ((u64)c << (6 * (k - 10)));
+    }
+}
+
+template <int SIDE, int NW> EWN_DEV u64 &occ_of(GState<NW> &s) { if constexpr (SIDE == 0) return s.occP; else return s.occN; }
+template <int SIDE, int NW> EWN_DEV u32 &alive_of(GState<NW> &s) { if constexpr (SIDE == 0) return s.aliveP; else return s.aliveN; }
+template <int SIDE, int NW> EWN_DEV u32 alive_of(const GState<NW> &s) { if constexpr (SIDE == 0) return s.aliveP; else return s.aliveN; }
+template <int SIDE, int NW> EWN_DEV int pos_of(const GState<NW> &s, int k) { if constexpr (SIDE == 0) return pos_get<NW>(s.posP, k); else return pos_get<NW>(s.posN, k); }
+template <int SIDE, int NW> EWN_DEV void set_pos_of(GState<NW> &s, int k, int c) { if constexpr (SIDE == 0) pos_set<NW>(s.posP, k, c); else pos_set<NW>(s.posN, k, c); }
+
+// board bytes -> registers (the 25/49-cell scan of restore_env_with_obs,
+// classical_policies/minimax.py:75-87, done once per lane per call)
+template <int NW, class BytePtr>
+EWN_DEV void decode_board(const Geom &g, BytePtr b, GState<NW> &s)
+{
+    s.occP = s.occN = 0; s.aliveP = s.aliveN = 0;
+    for (int w = 0; w < NW; w++) { s.posP[w] = 0; s.posN[w] = 0; }
+    for (int c = 0; c < g.cells; c++) {
+        int v = (int)(int8_t)b[c];
+        if (v > 0 && v <= g.CN) { s.occP |= 1ull << c; s.aliveP |= 1u << (v - 1); pos_set<NW>(s.posP, v - 1, c); }
+        else if (v < 0 && -v <= g.CN) { s.occN |= 1ull << c; s.aliveN |= 1u << (-v - 1); pos_set<NW>(s.posN, -v - 1, c); }
+    }
+}
+
+template <int NW, class BytePtr>
+EWN_DEV void encode_board(const Geom &g, const GState<NW> &s, BytePtr b)
+{
+    for (int c = 0; c < g.cells; c++) b[c] = 0;
+    for (int k = 0; k < g.CN; k++) {
+        if ((s.aliveP >> k) & 1u) b[pos_get<NW>(s.posP, k)] = (int8_t)(k + 1);
+        if ((s.aliveN >> k) & 1u) b[pos_get<NW>(s.posN, k)] = (int8_t)(-(k + 1));
+    }
+}
+
+// opponent_action's np.rot90(-board, 2) (envs/ewn.py:294): swap sides, mirror every cell index.
+template <int NW>
+EWN_DEV GState<NW> canonicalize(const Geom &g, const GState<NW> &s)
+{
+    GState<NW> c;
+    const int sh = 64 - g.cells;
+    c.occP = __brevll(s.occN) >> sh;
+    c.occN = __brevll(s.occP) >> sh;
+    c.aliveP = s.aliveN; c.aliveN = s.aliveP;
+    // fieldwise (cells-1) - pos: every 6-bit field holds a value <= cells-1, so no borrow crosses fields
+    u64 rep = 0;
+    for (int k = 0; k < 10; k++) rep |= (u64)(g.cells - 1) << (6 * k);
+    for (int w = 0; w < NW; w++) { c.posP[w] = rep - s.posN[w]; c.posN[w] = rep - s.posP[w]; }
+    return c;
+}
+
+// check_win, envs/ewn.py:131-142
+template <int NW>
+EWN_DEV bool is_win(const Geom &g, const GState<NW> &s)
+{
+    return (s.occN & 1ull) || (s.occP & g.corner_br) || s.occP == 0 || s.occN == 0;
+}
+
+// Dice -> candidate cubes (find_near_cube, envs/ewn.py:144-176; both players index by
+// |cube number|): the dice cube if alive, else the nearest alive larger / smaller one.
+struct CubeSel { bool exact, has_up, has_down; int k_exact, k_up, k_down; };
+
+EWN_DEV CubeSel select_cubes(u32 alive, int dice)
+{
+    CubeSel r;
+    const u32 bit = 1u << (dice - 1);
+    r.exact = (alive & bit) != 0;
+    r.k_exact = dice - 1;
+    const u32 up = alive & ~((bit << 1) - 1u);
+    const u32 down = alive & (bit - 1u);
+    r.has_up = up != 0; r.has_down = down != 0;
+    r.k_up = __ffs((int)up) - 1;
+    r.k_down = 31 - __clz((int)down);
+    return r;
+}
+
+// find_cube_to_move, envs/ewn.py:178-215 (returns -1 where the reference's assert fires)
+EWN_DEV int cube_to_move(const CubeSel &c, bool larger)
+{
+    if (c.exact) return c.k_exact;
+    if (larger) return c.has_up ? c.k_up : (c.has_down ? c.k_down : -1);
+    return c.has_down ? c.k_down : (c.has_up ? c.k_up : -1);
+}
+
+// is_within_board(update_position(...)), envs/ewn.py:301-323
+template <int SIDE>
+EWN_DEV bool dir_ok(const Geom &g, int c, int dir)
+{
+    const u64 b = 1ull << c;
+    const u64 colm = SIDE == 0 ? g.not_lastcol : g.not_firstcol;
+    const u64 rowm = SIDE == 0 ? g.not_lastrow : g.not_firstrow;
+    const bool col_ok = (b & colm) != 0, row_ok = (b & rowm) != 0;
+    return dir == 0 ? col_ok : (dir == 1 ? row_ok : (col_ok && row_ok));
+}
+
+template <int SIDE>
+EWN_DEV int dest_cell(const Geom &g, int c, int dir)
+{
+    const int d = dir == 0 ? 1 : (dir == 1 ? g.S : g.S + 1);
+    return SIDE == 0 ? c + d : c - d;
+}
+
+template <int SIDE, int NW>
+EWN_DEV void kill_at(const Geom &g, GState<NW> &s, int q)
+{
+    u32 a = alive_of<SIDE>(s);
+    for (int k = 0; k < g.CN; k++)
+        if (((a >> k) & 1u) && pos_of<SIDE>(s, k) == q) a &= ~(1u << k);
+    alive_of<SIDE>(s) = a;
+    occ_of<SIDE>(s) &= ~(1ull << q);
+}
+
+// execute_move / make_simulated_action for a move already known to stay on the board
+// (envs/ewn.py:252-261, 393-404): vacate, capture whatever is there (own cube included), place.
+template <int SIDE, int NW>
+EWN_DEV void apply_move(const Geom &g, GState<NW> &s, int k, int dir)
+{
+    const int p = pos_of<SIDE>(s, k);
+    const int q = dest_cell<SIDE>(g, p, dir);
+    const u64 bq = 1ull << q;
+    if (occ_of<1 - SIDE>(s) & bq) kill_at<1 - SIDE>(g, s, q);
+    else if (occ_of<SIDE>(s) & bq) kill_at<SIDE>(g, s, q);
+    occ_of<SIDE>(s) = (occ_of<SIDE>(s) & ~(1ull << p)) | bq;
+    set_pos_of<SIDE>(s, k, q);
+}
+
+// get_legal_actions, envs/ewn.py:338-375.  Visits the legal actions of SIDE in the
+// reference's list order; f(flag, k, dir) returns false to stop early.
+template <int SIDE, int NW, class F>
+EWN_DEV int for_each_legal(const Geom &g, const GState<NW> &s, int dice, F &&f)
+{
+    const CubeSel cs = select_cubes(alive_of<SIDE>(s), dice);
+    int n = 0;
+    bool go = true;
+    #pragma unroll
+    for (int slot = 0; slot < 2; slot++) {
+        bool have; int k, flag;
+        if (slot == 0) { have = cs.exact || cs.has_up; k = cs.exact ? cs.k_exact : cs.k_up; flag = cs.exact ? 0 : 1; }
+        else { have = !cs.exact && cs.has_down; k = cs.k_down; flag = 0; }
+        if (have && go) {
+            const int p = pos_of<SIDE>(s, k);
+            for (int dir = 0; dir < 3 && go; dir++)
+                if (dir_ok<SIDE>(g, p, dir)) { n++; go = f(flag, k, dir); }
+        }
+    }
+    return n;
+}
+
+// ---------------------------------------------------------------- heuristics
+
+// min over a side's cubes of max(S-1-row, S-1-col): BOTH sides are measured to the
+// bottom-right corner (envs/minimax_ewn.py:67-76).
+EWN_DEV int min_dist_br(const Geom &g, u64 m)
+{
+    int t = g.S - 1;
+    while (t > 0 && (m & g.sq[t]) == 0) t--;
+    return g.S - 1 - t;
+}
+
+// MinimaxEnv.evaluate, envs/minimax_ewn.py:29-213 (agent_player is TOP_LEFT in every
+// policy's private env).  fp64 in the reference's operation order; compile with
+// -ffp-contract=off so the multiply and the subtract stay two roundings.
+template <int NW>
+EWN_DEV double evaluate(const Geom &g, const GState<NW> &s, int heur)
+{
+    if ((s.occP & g.corner_br) || s.occN == 0) return 10.0;     // :42-44
+    if ((s.occN & 1ull) || s.occP == 0) return -10.0;           // :45-47
+    const int np = __popcll(s.occP), nn = __popcll(s.occN);
+    if (heur == 3) return (double)(-(np + nn));                 // attk :212
+    if (heur == 2) {                                            // two_min_dist :157-174
+        int sp = 0, sn = 0, tp = 0, tn = 0;
+        for (int t = g.S - 1; t >= 0; t--) {
+            const u64 ring = g.sq[t] & ~(t + 1 < g.S ? g.sq[t + 1] : 0ull);
+            int cp = __popcll(s.occP & ring), cn = __popcll(s.occN & ring);
+            const int d = g.S - 1 - t;
+            while (cp > 0 && tp < 2) { sp += d; tp++; cp--; }
+            while (cn > 0 && tn < 2) { sn += d; tn++; cn--; }
+        }
+        return (double)(sn - sp);
+    }
+    const int mdp = min_dist_br(g, s.occP), mdn = min_dist_br(g, s.occN);
+    if (heur == 1) return (double)((g.S - mdp) - (g.S - mdn));  // min_dist :126-127
+    const double a = (double)(g.S - mdp) * (1.0 / (double)np);  // hybrid :79-80
+    const double b = (double)(g.S - mdn) * (1.0 / (double)nn);  // :81-82
+    return (0.0 + a) - b;
+}
+
+// ---------------------------------------------------------------- expectiminimax
+
+// classical_policies/minimax.py:19-73, the recursion unrolled at compile time.
+// KIND 0 = MAX (TOP_LEFT moves), 1 = MIN (BOTTOM_RIGHT moves), 2 = CHANCE below MAX,
+// 3 = CHANCE below MIN.  Alpha/beta are passed by value THROUGH chance nodes exactly
+// as the reference does (unsound but behaviour-defining); depth also
+// decrements at chance nodes; the dice loop is the hard-coded 1..6 (App. D5).
+template <int NW, int DEPTH, int KIND, bool ROOT>
+__device__ double search(const Geom &g, const GState<NW> &s, int dice, double alpha, double beta, int heur, int &bflag, int &bdir)
+{
+    if constexpr (DEPTH == 0) {
+        return evaluate<NW>(g, s, heur);
+    } else {
+        if (is_win<NW>(g, s)) return evaluate<NW>(g, s, heur);
+        if constexpr (KIND >= 2) {
+            double expected = 0.0;
+            for (int d = 1; d <= 6; d++) {
+                const double v = search<NW, DEPTH - 1, (KIND == 2 ? 1 : 0), false>(g, s, d, alpha, beta, heur, bflag, bdir);
+                expected = expected + v / 6.0;
+            }
+            return expected;
+        } else {
+            constexpr int SIDE = KIND;
+            double best = SIDE == 0 ? -__builtin_inf() : __builtin_inf();
+            for_each_legal<SIDE, NW>(g, s, dice, [&](int flag, int k, int dir) -> bool {
+                GState<NW> c = s;
+                apply_move<SIDE, NW>(g, c, k, dir);
+                const double v = search<NW, DEPTH - 1, (SIDE == 0 ? 2 : 3), false>(g, c, dice, alpha, beta, heur, bflag, bdir);
+                if constexpr (SIDE == 0) {
+                    if (v > best) { best = v; if constexpr (ROOT) { bflag = flag; bdir = dir; } }
+                    if (best > alpha) alpha = best;
+                } else {
+                    if (v < best) best = v;
+                    if (best < beta) beta = best;
+                }
+                return !(beta <= alpha);
+            });
+            return best;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- RNG
+
+EWN_DEV void philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u32 k0, u32 k1, u32 (&out)[4])
+{
+    #pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const u32 h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const u32 h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const u32 n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Sequential u32 stream: word n = philox(ctr={n>>2, c1, c2, c3}, key)[n&3]
+struct PhiloxStream {
+    u32 c1, c2, c3, k0, k1, n;
+    u32 blk[4];
+    u32 have; // block index + 1 currently cached (0 = none)
+    EWN_DEV void init(u32 c1_, u32 c2_, u32 c3_, u64 key, u32 n_) { c1 = c1_; c2 = c2_; c3 = c3_; k0 = (u32)key; k1 = (u32)(key >> 32); n = n_; have = 0; }
+    EWN_DEV u32 next()
+    {
+        const u32 b = n >> 2;
+        if (have != b + 1) { philox4x32_10(b, c1, c2, c3, k0, k1, blk); have = b + 1; }
+        const u32 i = n & 3u;
+        n++;
+        return i == 0 ? blk[0] : (i == 1 ? blk[1] : (i == 2 ? blk[2] : blk[3]));
+    }
+};
+
+EWN_DEV u32 mt_temper(u32 y)
+{
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+EWN_DEV u32 mt_twist(u32 a, u32 b)
+{
+    const u32 y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+// np.random.seed(seed) followed by the first W outputs of the legacy MT19937 stream
+// (numpy mt19937_seed / mt19937_gen).  Output n (< 227) depends only on
+// the seeded words s[n], s[n+1], s[n+397], so one pass of the seeding recurrence
+// (397+W steps) yields the window without ever materialising the 624-word state.
+// `win` doubles as the temporary for s[0..W-1].
+EWN_DEV void mt_fill_window(u32 seed, int W, u32 *win)
+{
+    u32 s = seed;
+    for (int i = 0; i < W; i++) { win[i] = s; s = 1812433253u * (s ^ (s >> 30)) + (u32)i + 1u; }
+    const u32 sW = s; // s[W]
+    for (int i = W; i < 397; i++) s = 1812433253u * (s ^ (s >> 30)) + (u32)i + 1u;
+    // s == s[397]
+    for (int n = 0; n < W; n++) {
+        const u32 a = win[n], b = (n + 1 < W) ? win[n + 1] : sW;
+        win[n] = mt_temper(s ^ mt_twist(a, b));
+        s = 1812433253u * (s ^ (s >> 30)) + (u32)(397 + n) + 1u;
+    }
+}
+
+// Output n of the same stream for W <= n < 454, memory-free (rare path: an episode
+// that consumes more draws than the window holds).  For 227 <= n < 454 the word
+// x[n+397] is itself a first-generation output of the recurrence.
+__device__ __noinline__ u32 mt_output_closed(u32 seed, u32 n)
+{
+    const u32 j = n >= 227u ? n - 227u : 0u;
+    u32 s = seed, sn = 0, sn1 = 0, sj = 0, sj1 = 0, sj397 = 0, sn397 = 0;
+    for (u32 i = 0; i < 624u; i++) {
+        if (i == n) sn = s;
+        if (i == n + 1u) sn1 = s;
+        if (i == n + 397u) sn397 = s;
+        if (i == j) sj = s;
+        if (i == j + 1u) sj1 = s;
+        if (i == j + 397u) sj397 = s;
+        s = 1812433253u * (s ^ (s >> 30)) + i + 1u;
+    }
+    const u32 x397 = n >= 227u ? (sj397 ^ mt_twist(sj, sj1)) : sn397;
+    return mt_temper(x397 ^ mt_twist(sn, sn1));
+}
+
+#define EWN_RNG_HDR 4 // words: seed, draw index, next_seed, flags(bit0 = MT draw index >= 454: unsupported)
+
+// One lane's dice stream for the duration of a kernel.
+struct LaneRng {
+    int kind;         // 0 MT19937 window, 1 Philox
+    u32 seed, n, flags;
+    u32 W;
+    const u32 *win;
+    PhiloxStream ps;
+    EWN_DEV void load(int kind_, const u32 *hdr, u32 W_, u64 key)
+    {
+        kind = kind_; seed = hdr[0]; n = hdr[1]; flags = hdr[3]; W = W_; win = hdr + EWN_RNG_HDR;
+        if (kind == 1) ps.init(seed, 0u, 0x454E5631u, key, n);
+    }
+    EWN_DEV void store(u32 *hdr) const { hdr[1] = kind == 1 ? ps.n : n; hdr[3] = flags; }
+    EWN_DEV u32 draws() const { return kind == 1 ? ps.n : n; }
+    EWN_DEV u32 next()
+    {
+        if (kind == 1) return ps.next();
+        u32 v;
+        if (n < W) v = win[n];
+        else if (n < 454u) v = mt_output_closed(seed, n);
+        else { v = 0; flags |= 1u; }
+        n++;
+        return v;
+    }
+    // np.random.randint(lo, hi) of the legacy RandomState: masked rejection on 32-bit
+    // draws; a one-element range consumes no draw.
+    EWN_DEV int randint(int lo, int hi)
+    {
+        const u32 rng = (u32)(hi - lo - 1);
+        if (rng == 0) return lo;
+        u32 mask = rng;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        u32 v;
+        int guard = 0;
+        do { v = next() & mask; } while (v > rng && ++guard < 4096);
+        return lo + (int)(v > rng ? 0u : v);
+    }
+};

@@ -1,0 +1,720 @@
+// ewn_kernels.hip -- gfx950 kernels and the C ABI (include/ewn_hip.h) of libewn_hip.so.
+//
+// Layout in HBM: board int8 [N][S*S] (one contiguous row per lane, so a block of 256
+// lanes is one contiguous 6.4 KB (5x5) / 12.5 KB (7x7) span that is copied to and
+// from LDS with coalesced dword accesses), dice int8 [N], done u8 [N], rng u32
+// [N][4 + W].  One thread owns one lane (game); the wavefront is the unit of
+// scheduling, not the unit of work -- a 25-cell board would leave 39 of 64 lanes
+// idle if a whole wavefront served one game.
+#include "ewn_core.hpp"
+#include "../../include/ewn_hip.h"
+
+#define BS 256
+
+struct KCfg {
+    int N, opp, depth, heur, rng_kind, shaped, autoreset, refresh, lane_offset, nsim_total;
+    u32 seed_stride, W, rng_words;
+    double reward, illegal_reward;
+    u64 key;
+};
+
+struct KState {
+    int8_t *board; int8_t *dice; uint8_t *done; u32 *rng; double *prev_score; int32_t *tolerance;
+};
+
+struct KOut {
+    double *reward; uint8_t *terminated; uint8_t *truncated; uint8_t *info; int8_t *tboard; int8_t *tdice;
+};
+
+struct KScratch { // split-phase step (MCTS opponent)
+    uint8_t *phase; int8_t *cboard; int8_t *cdice; int8_t *act; int32_t *wins; u32 *obs_id;
+};
+
+// ---------------------------------------------------------------- LDS staging
+
+// Copy nbytes between global and LDS with the whole block: dwords when both sides are
+// 4-byte aligned (consecutive threads -> consecutive dwords), bytes for the tail.
+__device__ __forceinline__ void block_copy_in(int8_t *lds, const int8_t *g, int nbytes)
+{
+    const int nw = (((uintptr_t)g & 3) == 0) ? nbytes >> 2 : 0;
+    for (int i = threadIdx.x; i < nw; i += blockDim.x) ((u32 *)lds)[i] = ((const u32 *)g)[i];
+    for (int i = (nw << 2) + threadIdx.x; i < nbytes; i += blockDim.x) lds[i] = g[i];
+}
+
+__device__ __forceinline__ void block_copy_out(int8_t *g, const int8_t *lds, int nbytes)
+{
+    const int nw = (((uintptr_t)g & 3) == 0) ? nbytes >> 2 : 0;
+    for (int i = threadIdx.x; i < nw; i += blockDim.x) ((u32 *)g)[i] = ((const u32 *)lds)[i];
+    for (int i = (nw << 2) + threadIdx.x; i < nbytes; i += blockDim.x) g[i] = lds[i];
+}
+
+// ---------------------------------------------------------------- per-lane pieces
+
+// reset(seed) + setup_game, envs/ewn.py:488-494, 94-108
+template <int NW>
+__device__ void lane_reset(const Geom &g, const KCfg &c, u32 seed, u32 *hdr, GState<NW> &s, int &dice, LaneRng &r)
+{
+    hdr[0] = seed; hdr[1] = 0; hdr[2] = seed + c.seed_stride; hdr[3] = 0;
+    if (c.rng_kind == 0) mt_fill_window(seed, (int)c.W, hdr + EWN_RNG_HDR);
+    r.load(c.rng_kind, hdr, c.W, c.key);
+    decode_board<NW>(g, g.init, s);
+    dice = r.randint(1, g.CN + 1); // roll_dice :90-91
+}
+
+struct StepRes { double reward; int term, trunc, info; };
+
+// Agent half of step(): envs/ewn.py:438-458 and training_ewn.py:44-66.
+// Returns true when the opponent must still reply.
+template <int NW>
+__device__ bool step_agent(const Geom &g, const KCfg &c, GState<NW> &s, int &dice, int flag, int dir, LaneRng &r,
+                           int32_t *tol, StepRes &o)
+{
+    o.reward = 0.0; o.term = 0; o.trunc = 0; o.info = EWN_INFO_NONE;
+    const CubeSel cs = select_cubes(s.aliveP, dice);
+    const int k = cube_to_move(cs, flag == 1);
+    const bool valid = k >= 0 && dir >= 0 && dir <= 2 && dir_ok<0>(g, pos_of<0>(s, k), dir);
+    if (!valid) {
+        if (c.shaped) {
+            const int t = *tol - 1;
+            *tol = t;
+            if (t <= 0) { o.reward = -c.reward; o.term = 1; o.trunc = 1; o.info = EWN_INFO_INVALID_PLAYER; }
+            else { o.reward = c.illegal_reward; o.info = EWN_INFO_TOLERANCE; }
+        } else { o.reward = -c.reward; o.term = 1; o.trunc = 1; o.info = EWN_INFO_INVALID_PLAYER; }
+        return false;
+    }
+    apply_move<0, NW>(g, s, k, dir);
+    if (is_win<NW>(g, s)) { o.reward = c.reward; o.term = 1; o.info = EWN_INFO_WON; return false; }
+    dice = r.randint(1, g.CN + 1); // the opponent's dice, :458
+    return true;
+}
+
+// Opponent half: envs/ewn.py:464-486, training_ewn.py:75-99.
+template <int NW>
+__device__ void step_opponent(const Geom &g, const KCfg &c, GState<NW> &s, int &dice, int oflag, int odir, LaneRng &r,
+                              double *prev_score, StepRes &o)
+{
+    const CubeSel cs = select_cubes(s.aliveN, dice);
+    const int k = cube_to_move(cs, oflag == 1);
+    const bool valid = k >= 0 && odir >= 0 && odir <= 2 && dir_ok<1>(g, pos_of<1>(s, k), odir);
+    if (!valid) { o.reward = 0.0; o.term = 1; o.trunc = 1; o.info = EWN_INFO_INVALID_OPP; return; }
+    apply_move<1, NW>(g, s, k, odir);
+    if (is_win<NW>(g, s)) { o.reward = -c.reward; o.term = 1; o.info = EWN_INFO_LOST; return; }
+    dice = r.randint(1, g.CN + 1); // :483
+    if (c.shaped) {
+        const double cur = evaluate<NW>(g, s, EWN_H_HYBRID);
+        o.reward = cur - *prev_score;
+        *prev_score = cur;
+    }
+}
+
+// RandomAgent.predict on the live env (classical_policies/random_policy.py:11-15):
+// uniform index into BOTTOM_RIGHT's legal list, drawn from the lane's own stream.
+template <int NW>
+__device__ void policy_random(const Geom &g, const GState<NW> &s, int dice, LaneRng &r, int &oflag, int &odir)
+{
+    const int n = for_each_legal<1, NW>(g, s, dice, [](int, int, int) { return true; });
+    const int pick = r.randint(0, n);
+    int i = 0;
+    oflag = 0; odir = 0;
+    for_each_legal<1, NW>(g, s, dice, [&](int flag, int, int dir) { if (i == pick) { oflag = flag; odir = dir; } i++; return i <= pick; });
+}
+
+template <int NW, int DEPTH>
+__device__ void policy_minimax(const Geom &g, const GState<NW> &s, int dice, int heur, int &oflag, int &odir, double *value)
+{
+    const GState<NW> cst = canonicalize<NW>(g, s); // the policy always plays TOP_LEFT (envs/ewn.py:291-295)
+    oflag = 0; odir = 0;
+    const double v = search<NW, DEPTH, 0, true>(g, cst, dice, -__builtin_inf(), __builtin_inf(), heur, oflag, odir);
+    if (value) *value = v;
+}
+
+template <int NW>
+__device__ void policy_minimax_rt(const Geom &g, const GState<NW> &s, int dice, int depth, int heur, int &oflag, int &odir)
+{
+    switch (depth) {
+    case 1: policy_minimax<NW, 1>(g, s, dice, heur, oflag, odir, nullptr); break;
+    case 2: policy_minimax<NW, 2>(g, s, dice, heur, oflag, odir, nullptr); break;
+    case 3: policy_minimax<NW, 3>(g, s, dice, heur, oflag, odir, nullptr); break;
+    case 4: policy_minimax<NW, 4>(g, s, dice, heur, oflag, odir, nullptr); break;
+    case 5: policy_minimax<NW, 5>(g, s, dice, heur, oflag, odir, nullptr); break;
+    default: policy_minimax<NW, 6>(g, s, dice, heur, oflag, odir, nullptr); break;
+    }
+}
+
+// ---------------------------------------------------------------- reset / init kernels
+
+template <int NW>
+__global__ __launch_bounds__(BS) void k_reset(Geom g, KCfg c, KState st, const u32 *seeds, const uint8_t *mask)
+{
+    extern __shared__ int8_t lds[];
+    const int lane0 = blockIdx.x * BS, nl = min(BS, c.N - lane0), lane = lane0 + threadIdx.x;
+    block_copy_in(lds, st.board + (size_t)lane0 * g.cells, nl * g.cells);
+    __syncthreads();
+    if (lane < c.N && (!mask || mask[lane])) {
+        u32 *hdr = st.rng + (size_t)lane * c.rng_words;
+        const u32 seed = seeds ? seeds[lane] : hdr[2];
+        GState<NW> s; int dice; LaneRng r;
+        lane_reset<NW>(g, c, seed, hdr, s, dice, r);
+        r.store(hdr);
+        st.dice[lane] = (int8_t)dice;
+        st.done[lane] = 0;
+        if (c.shaped && c.refresh && st.prev_score) st.prev_score[lane] = evaluate<NW>(g, s, EWN_H_HYBRID);
+        encode_board<NW>(g, s, lds + threadIdx.x * g.cells);
+    }
+    __syncthreads();
+    block_copy_out(st.board + (size_t)lane0 * g.cells, lds, nl * g.cells);
+}
+
+template <int NW>
+__global__ __launch_bounds__(BS) void k_init_aux(Geom g, KCfg c, KState st, int tol0)
+{
+    const int lane = blockIdx.x * BS + threadIdx.x;
+    if (lane >= c.N) return;
+    st.done[lane] = 0;
+    u32 *hdr = st.rng + (size_t)lane * c.rng_words;
+    hdr[0] = hdr[1] = hdr[2] = hdr[3] = 0;
+    if (st.prev_score) {
+        GState<NW> s;
+        decode_board<NW>(g, g.init, s);
+        st.prev_score[lane] = evaluate<NW>(g, s, EWN_H_HYBRID); // training_ewn.py:35
+    }
+    if (st.tolerance) st.tolerance[lane] = tol0;
+}
+
+// ---------------------------------------------------------------- step kernels
+
+// PHASE 0: fused (agent + in-thread opponent policy + finish)
+// PHASE 1: agent half only; a lane that still needs the opponent's reply leaves its
+//          canonical observation in scratch for a policy kernel (sc.phase[lane] = 1)
+// PHASE 2: opponent half for the lanes with sc.phase[lane] == 1, action taken from scratch
+template <int NW, int PHASE>
+__global__ __launch_bounds__(BS) void k_step(Geom g, KCfg c, KState st, const int8_t *actions, KOut out, KScratch sc)
+{
+    extern __shared__ int8_t lds[];
+    int8_t *lds_t = lds + BS * g.cells; // terminal-observation staging
+    const int lane0 = blockIdx.x * BS, nl = min(BS, c.N - lane0), lane = lane0 + threadIdx.x;
+    block_copy_in(lds, st.board + (size_t)lane0 * g.cells, nl * g.cells);
+    if (PHASE == 2 && out.tboard) block_copy_in(lds_t, out.tboard + (size_t)lane0 * g.cells, nl * g.cells);
+    __syncthreads();
+    if (lane < c.N) {
+        int8_t *mine = lds + threadIdx.x * g.cells, *mine_t = lds_t + threadIdx.x * g.cells;
+        const bool frozen = st.done[lane] != 0;
+        const bool skip = PHASE == 2 && (frozen || sc.phase[lane] == 0); // settled by the pre phase
+        if (!skip) {
+            int dice = st.dice[lane];
+            StepRes o; o.reward = 0.0; o.term = 0; o.trunc = 0; o.info = EWN_INFO_NONE;
+            bool settled = true; // this launch produces the lane's step result
+            if (frozen) {
+                o.term = 1;
+                // no reference counterpart: stepping a finished game is undefined upstream; the lane stays put
+                if (PHASE == 1) sc.phase[lane] = 0;
+                if (out.tboard) for (int i = 0; i < g.cells; i++) mine_t[i] = mine[i];
+                if (out.tdice) out.tdice[lane] = (int8_t)dice;
+            } else {
+                u32 *hdr = st.rng + (size_t)lane * c.rng_words;
+                LaneRng r; r.load(c.rng_kind, hdr, c.W, c.key);
+                GState<NW> s;
+                decode_board<NW>(g, mine, s);
+                bool reply;
+                int oflag = 0, odir = 0;
+                if (PHASE != 2) {
+                    reply = step_agent<NW>(g, c, s, dice, actions[2 * lane], actions[2 * lane + 1], r,
+                                           st.tolerance ? st.tolerance + lane : nullptr, o);
+                } else {
+                    reply = true;
+                    oflag = sc.act[2 * lane]; odir = sc.act[2 * lane + 1];
+                }
+                if (PHASE == 1) {
+                    sc.phase[lane] = reply ? 1 : 0;
+                    if (reply) {
+                        const GState<NW> cst = canonicalize<NW>(g, s);
+                        encode_board<NW>(g, cst, sc.cboard + (size_t)lane * g.cells);
+                        sc.cdice[lane] = (int8_t)dice;
+                        sc.obs_id[lane] = hdr[0] * 0x9E3779B1u + r.draws();
+                        settled = false;
+                    }
+                } else if (reply) {
+                    if (PHASE == 0) {
+                        if (c.opp == EWN_OPP_RANDOM) policy_random<NW>(g, s, dice, r, oflag, odir);
+                        else policy_minimax_rt<NW>(g, s, dice, c.depth, c.heur, oflag, odir);
+                    }
+                    step_opponent<NW>(g, c, s, dice, oflag, odir, r, st.prev_score ? st.prev_score + lane : nullptr, o);
+                }
+                if (settled) {
+                    if (out.tboard) encode_board<NW>(g, s, mine_t);
+                    if (out.tdice) out.tdice[lane] = (int8_t)dice;
+                    if (o.term) {
+                        if (c.autoreset) {
+                            lane_reset<NW>(g, c, hdr[2], hdr, s, dice, r);
+                            if (c.shaped && c.refresh && st.prev_score) st.prev_score[lane] = evaluate<NW>(g, s, EWN_H_HYBRID);
+                        } else st.done[lane] = 1;
+                    }
+                }
+                r.store(hdr);
+                encode_board<NW>(g, s, mine);
+                st.dice[lane] = (int8_t)dice;
+            }
+            if (settled) {
+                out.reward[lane] = o.reward; out.terminated[lane] = (uint8_t)o.term;
+                out.truncated[lane] = (uint8_t)o.trunc; out.info[lane] = (uint8_t)o.info;
+            }
+        }
+    }
+    __syncthreads();
+    block_copy_out(st.board + (size_t)lane0 * g.cells, lds, nl * g.cells);
+    if (out.tboard) block_copy_out(out.tboard + (size_t)lane0 * g.cells, lds_t, nl * g.cells);
+}
+
+// ---------------------------------------------------------------- stateless queries
+
+template <int NW>
+__global__ __launch_bounds__(BS) void k_legal(Geom g, int M, const int8_t *boards, const int8_t *dice, int player, int8_t *acts,
+                                              int8_t *n_acts, int8_t *cube_small, int8_t *cube_large, uint8_t *win)
+{
+    const int m = blockIdx.x * BS + threadIdx.x;
+    if (m >= M) return;
+    GState<NW> s;
+    decode_board<NW>(g, boards + (size_t)m * g.cells, s);
+    const int d = dice[m];
+    if (win) win[m] = is_win<NW>(g, s) ? 1 : 0;
+    const u32 alive = player == 1 ? s.aliveP : s.aliveN;
+    int n = 0;
+    int8_t la[12];
+    for (int i = 0; i < 12; i++) la[i] = -1;
+    if (alive != 0 && d >= 1 && d <= g.CN) {
+        auto rec = [&](int flag, int, int dir) { for (int i = 0; i < 6; i++) if (i == n) { la[2 * i] = (int8_t)flag; la[2 * i + 1] = (int8_t)dir; } n++; return true; };
+        if (player == 1) for_each_legal<0, NW>(g, s, d, rec); else for_each_legal<1, NW>(g, s, d, rec);
+        const CubeSel cs = select_cubes(alive, d);
+        if (cube_small) cube_small[m] = (int8_t)(cube_to_move(cs, false) + 1);
+        if (cube_large) cube_large[m] = (int8_t)(cube_to_move(cs, true) + 1);
+    } else {
+        if (cube_small) cube_small[m] = 0;
+        if (cube_large) cube_large[m] = 0;
+    }
+    if (acts) for (int i = 0; i < 12; i++) acts[(size_t)m * 12 + i] = la[i];
+    if (n_acts) n_acts[m] = (int8_t)n;
+}
+
+template <int NW>
+__global__ __launch_bounds__(BS) void k_evaluate(Geom g, int M, const int8_t *boards, int heur, double *out)
+{
+    const int m = blockIdx.x * BS + threadIdx.x;
+    if (m >= M) return;
+    GState<NW> s;
+    decode_board<NW>(g, boards + (size_t)m * g.cells, s);
+    out[m] = evaluate<NW>(g, s, heur);
+}
+
+template <int NW, int DEPTH>
+__global__ __launch_bounds__(BS) void k_predict_minimax(Geom g, int M, const int8_t *boards, const int8_t *dice, int heur,
+                                                        int8_t *actions, double *values)
+{
+    const int m = blockIdx.x * BS + threadIdx.x;
+    if (m >= M) return;
+    GState<NW> s;
+    decode_board<NW>(g, boards + (size_t)m * g.cells, s);
+    int f = -1, d = -1;
+    double v = 0.0;
+    const int dc = dice[m];
+    if (s.aliveP != 0 && dc >= 1 && dc <= g.CN)
+        v = search<NW, DEPTH, 0, true>(g, s, dc, -__builtin_inf(), __builtin_inf(), heur, f, d);
+    actions[2 * m] = (int8_t)f; actions[2 * m + 1] = (int8_t)d;
+    if (values) values[m] = v;
+}
+
+template <int NW>
+__global__ __launch_bounds__(BS) void k_predict_random(Geom g, int M, const int8_t *boards, const int8_t *dice, u64 key, u32 step,
+                                                       int lane_offset, int8_t *actions)
+{
+    const int m = blockIdx.x * BS + threadIdx.x;
+    if (m >= M) return;
+    GState<NW> s;
+    decode_board<NW>(g, boards + (size_t)m * g.cells, s);
+    const int d = dice[m];
+    int f = 0, dr = 0;
+    if (s.aliveP != 0 && d >= 1 && d <= g.CN) {
+        const int n = for_each_legal<0, NW>(g, s, d, [](int, int, int) { return true; });
+        u32 o[4];
+        philox4x32_10(step, (u32)(lane_offset + m), 0x41474E54u, 0u, (u32)key, (u32)(key >> 32), o);
+        const int pick = (int)__umulhi(o[0], (u32)n);
+        int i = 0;
+        for_each_legal<0, NW>(g, s, d, [&](int flag, int, int dir) { if (i == pick) { f = flag; dr = dir; } i++; return i <= pick; });
+    }
+    actions[2 * m] = (int8_t)f; actions[2 * m + 1] = (int8_t)dr;
+}
+
+// ---------------------------------------------------------------- flat Monte-Carlo ("MCTS")
+
+template <int NW>
+__global__ __launch_bounds__(BS) void k_mcts_init(Geom g, int M, const int8_t *boards, const int8_t *dice, const uint8_t *active,
+                                                  int32_t *wins)
+{
+    const int m = blockIdx.x * BS + threadIdx.x;
+    if (m >= M) return;
+    int n = 0;
+    if (!active || active[m]) {
+        GState<NW> s;
+        decode_board<NW>(g, boards + (size_t)m * g.cells, s);
+        const int d = dice[m];
+        if (s.aliveP != 0 && d >= 1 && d <= g.CN && !is_win<NW>(g, s))
+            n = for_each_legal<0, NW>(g, s, d, [](int, int, int) { return true; });
+    }
+    for (int i = 0; i < 6; i++) wins[(size_t)m * 6 + i] = i < n ? 0 : -1;
+}
+
+EWN_DEV int ps_below(PhiloxStream &ps, int n)
+{
+    if (n <= 1) return 0;
+    const u32 rng = (u32)(n - 1);
+    u32 mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4;
+    u32 v;
+    int guard = 0;
+    do { v = ps.next() & mask; } while (v > rng && ++guard < 4096);
+    return (int)(v > rng ? 0u : v);
+}
+
+template <int SIDE, int NW>
+EWN_DEV void rollout_ply(const Geom &g, GState<NW> &s, PhiloxStream &ps)
+{
+    const int d = 1 + ps_below(ps, 6); // random.randint(1, 6), classical_policies/mcts.py:29
+    const int n = for_each_legal<SIDE, NW>(g, s, d, [](int, int, int) { return true; });
+    const int pick = ps_below(ps, n);
+    int i = 0, mk = 0, md = 0;
+    for_each_legal<SIDE, NW>(g, s, d, [&](int, int k, int dir) { if (i == pick) { mk = k; md = dir; } i++; return i <= pick; });
+    if (n > 0) apply_move<SIDE, NW>(g, s, mk, md);
+}
+
+// one thread = one playout: (observation m, root move i, playout r); classical_policies/mcts.py:21-45
+template <int NW>
+__global__ __launch_bounds__(BS) void k_mcts_rollout(Geom g, int M, int total, const int8_t *boards, const int8_t *dice,
+                                                     const u32 *obs_id, u64 key, int32_t *wins)
+{
+    const long long idx = (long long)blockIdx.x * BS + threadIdx.x;
+    const long long per = 6ll * total;
+    if (idx >= (long long)M * per) return;
+    const int m = (int)(idx / per), rem = (int)(idx % per), i = rem / total, r = rem % total;
+    if (wins[(size_t)m * 6 + i] < 0) return; // no such root move (or inactive lane); set by k_mcts_init, never by this kernel
+    GState<NW> s;
+    decode_board<NW>(g, boards + (size_t)m * g.cells, s);
+    {
+        int j = 0, mk = 0, md = 0;
+        for_each_legal<0, NW>(g, s, dice[m], [&](int, int k, int dir) { if (j == i) { mk = k; md = dir; } j++; return j <= i; });
+        apply_move<0, NW>(g, s, mk, md);
+    }
+    PhiloxStream ps;
+    ps.init(obs_id ? obs_id[m] : (u32)m, (u32)(i * total + r), 0x4D435453u, key, 0u);
+    int cur = 1; // BOTTOM_RIGHT replies first, mcts.py:26
+    for (int ply = 0; ply < 1024 && !is_win<NW>(g, s); ply++) {
+        if (cur == 0) rollout_ply<0, NW>(g, s, ps); else rollout_ply<1, NW>(g, s, ps);
+        cur ^= 1;
+    }
+    if ((s.occP & g.corner_br) || s.occN == 0) atomicAdd(&wins[(size_t)m * 6 + i], 1); // mcts.py:39-41
+}
+
+template <int NW>
+__global__ __launch_bounds__(BS) void k_mcts_pick(Geom g, int M, const int8_t *boards, const int8_t *dice, const int32_t *wins,
+                                                  int8_t *actions)
+{
+    const int m = blockIdx.x * BS + threadIdx.x;
+    if (m >= M) return;
+    int best = -1, bw = -1;
+    for (int i = 0; i < 6; i++) { const int w = wins[(size_t)m * 6 + i]; if (w > bw) { bw = w; best = i; } } // np.argmax: first max
+    int f = 0, dr = 0;
+    if (best >= 0) {
+        GState<NW> s;
+        decode_board<NW>(g, boards + (size_t)m * g.cells, s);
+        int j = 0;
+        for_each_legal<0, NW>(g, s, dice[m], [&](int flag, int, int dir) { if (j == best) { f = flag; dr = dir; } j++; return j <= best; });
+    }
+    actions[2 * m] = (int8_t)f; actions[2 * m + 1] = (int8_t)dr;
+}
+
+// ---------------------------------------------------------------- host side: C ABI
+
+static bool make_geom(int S, int L, Geom &g)
+{
+    if (S < 3 || S > EWN_MAX_BOARD || L < 1 || L >= S - 1) return false; // assert cube_layer < board_size - 1, envs/ewn.py:47
+    const int CN = L * (L + 1) / 2;
+    if (CN > EWN_MAX_CUBES) return false;
+    g.S = S; g.L = L; g.CN = CN; g.cells = S * S;
+    g.not_lastcol = g.not_lastrow = g.not_firstcol = g.not_firstrow = 0;
+    for (int t = 0; t < 8; t++) g.sq[t] = 0;
+    for (int i = 0; i < S; i++)
+        for (int j = 0; j < S; j++) {
+            const u64 b = 1ull << (i * S + j);
+            if (j < S - 1) g.not_lastcol |= b;
+            if (i < S - 1) g.not_lastrow |= b;
+            if (j > 0) g.not_firstcol |= b;
+            if (i > 0) g.not_firstrow |= b;
+            for (int t = 0; t < S; t++) if (i >= t && j >= t) g.sq[t] |= b;
+        }
+    g.corner_br = 1ull << (S * S - 1);
+    for (int c = 0; c < 64; c++) g.init[c] = 0;
+    int cnt = 1;
+    for (int i = 1; i <= L; i++)
+        for (int j = 0; j < i; j++) {
+            g.init[j * S + (i - j - 1)] = (int8_t)cnt;
+            g.init[(S - 1 - j) * S + (S - i + j)] = (int8_t)(-cnt);
+            cnt++;
+        }
+    return true;
+}
+
+static int check_cfg(const ewn_config *cfg, Geom &g, KCfg &k)
+{
+    if (!cfg) return EWN_ENULL;
+    if (cfg->board_size > EWN_MAX_BOARD && cfg->cube_layer >= 1 && cfg->cube_layer < cfg->board_size - 1) return EWN_EUNSUPPORTED;
+    if (!make_geom(cfg->board_size, cfg->cube_layer, g)) return EWN_EINVAL;
+    if (cfg->n_lanes < 1) return EWN_EINVAL;
+    if (cfg->opponent_kind < 0 || cfg->opponent_kind > EWN_OPP_MCTS) return EWN_EINVAL;
+    if (cfg->rng_kind != EWN_RNG_MT19937 && cfg->rng_kind != EWN_RNG_PHILOX) return EWN_EINVAL;
+    if (cfg->opponent_kind == EWN_OPP_MINIMAX) {
+        if (cfg->max_depth < 1 || cfg->max_depth > EWN_MAX_DEPTH) return EWN_EUNSUPPORTED;
+        if (cfg->heuristic < 0 || cfg->heuristic > EWN_H_ATTK) return EWN_EUNSUPPORTED;
+    }
+    // the searches and rollouts roll dice 1..6 (minimax.py:68, mcts.py:29): cube_num < 6 raises IndexError upstream
+    if (cfg->opponent_kind != EWN_OPP_RANDOM && g.CN < 6) return EWN_EUNSUPPORTED;
+    if (cfg->opponent_kind == EWN_OPP_MCTS && (cfg->num_simulations < 1 || cfg->num_env_copies < 1)) return EWN_EINVAL;
+    u32 W = cfg->mt_window ? cfg->mt_window : 128u;
+    if (W < 16 || W > EWN_MT_WINDOW_MAX) return EWN_EINVAL;
+    k.N = cfg->n_lanes; k.opp = cfg->opponent_kind; k.depth = cfg->max_depth; k.heur = cfg->heuristic;
+    k.rng_kind = cfg->rng_kind; k.shaped = cfg->shaped; k.autoreset = cfg->autoreset; k.refresh = cfg->shaped_refresh_on_reset;
+    k.lane_offset = cfg->lane_offset; k.nsim_total = cfg->num_simulations * cfg->num_env_copies;
+    k.seed_stride = cfg->seed_stride; k.W = W;
+    k.rng_words = EWN_RNG_HDR + (cfg->rng_kind == EWN_RNG_MT19937 ? W : 0u);
+    k.reward = cfg->reward; k.illegal_reward = cfg->illegal_move_reward; k.key = cfg->philox_key;
+    return EWN_OK;
+}
+
+static int launch_status()
+{
+    return hipGetLastError() == hipSuccess ? EWN_OK : EWN_ELAUNCH;
+}
+
+#define GRID(n) dim3((unsigned)(((long long)(n) + BS - 1) / BS))
+#define BY_NW(g, expr1, expr2) do { if ((g).CN <= 10) { expr1; } else { expr2; } } while (0)
+
+template <int NW>
+static void launch_minimax(const Geom &g, int M, const int8_t *boards, const int8_t *dice, int depth, int heur, int8_t *actions,
+                           double *values, hipStream_t s)
+{
+    switch (depth) {
+    case 1: k_predict_minimax<NW, 1><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, heur, actions, values); break;
+    case 2: k_predict_minimax<NW, 2><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, heur, actions, values); break;
+    case 3: k_predict_minimax<NW, 3><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, heur, actions, values); break;
+    case 4: k_predict_minimax<NW, 4><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, heur, actions, values); break;
+    case 5: k_predict_minimax<NW, 5><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, heur, actions, values); break;
+    default: k_predict_minimax<NW, 6><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, heur, actions, values); break;
+    }
+}
+
+extern "C" {
+
+int ewn_abi_version(void) { return EWN_ABI_VERSION; }
+
+const char *ewn_strerror(int code)
+{
+    switch (code) {
+    case EWN_OK: return "ok";
+    case EWN_EINVAL: return "invalid argument or configuration";
+    case EWN_ENULL: return "required pointer is NULL";
+    case EWN_ELAUNCH: return "kernel launch failed";
+    case EWN_EUNSUPPORTED: return "configuration valid upstream but not supported by this build";
+    default: return "unknown error";
+    }
+}
+
+int ewn_rng_words(const ewn_config *cfg)
+{
+    Geom g; KCfg k;
+    const int rc = check_cfg(cfg, g, k);
+    return rc ? rc : (int)k.rng_words;
+}
+
+int64_t ewn_step_scratch_bytes(const ewn_config *cfg)
+{
+    Geom g; KCfg k;
+    const int rc = check_cfg(cfg, g, k);
+    if (rc) return rc;
+    if (cfg->opponent_kind != EWN_OPP_MCTS) return 0;
+    // phase u8 | cdice i8 | act i8x2 | (pad to 8) | obs_id u32 | wins i32x6 | cboard i8[cells]
+    const int64_t N = k.N;
+    return ((N * 4 + 7) / 8) * 8 + N * 4 + N * 24 + N * g.cells;
+}
+
+static void carve_scratch(const Geom &g, const KCfg &k, void *scratch, KScratch &sc)
+{
+    int8_t *p = (int8_t *)scratch;
+    const int64_t N = k.N;
+    sc.phase = (uint8_t *)p;
+    sc.cdice = p + N;
+    sc.act = p + 2 * N;
+    p += ((N * 4 + 7) / 8) * 8;
+    sc.obs_id = (u32 *)p; p += N * 4;
+    sc.wins = (int32_t *)p; p += N * 24;
+    sc.cboard = p;
+}
+
+static KState kstate(const ewn_state *st)
+{
+    KState s = { st->board, st->dice, st->done, st->rng, st->prev_score, st->tolerance };
+    return s;
+}
+
+int ewn_init_aux(const ewn_config *cfg, const ewn_state *st, void *stream)
+{
+    Geom g; KCfg k;
+    int rc = check_cfg(cfg, g, k);
+    if (rc) return rc;
+    if (!st || !st->done || !st->rng) return EWN_ENULL;
+    if (cfg->shaped && (!st->prev_score || !st->tolerance)) return EWN_ENULL;
+    hipStream_t s = (hipStream_t)stream;
+    BY_NW(g, (k_init_aux<1><<<GRID(k.N), BS, 0, s>>>(g, k, kstate(st), cfg->illegal_move_tolerance)),
+          (k_init_aux<2><<<GRID(k.N), BS, 0, s>>>(g, k, kstate(st), cfg->illegal_move_tolerance)));
+    return launch_status();
+}
+
+int ewn_reset(const ewn_config *cfg, const ewn_state *st, const uint32_t *seeds, const uint8_t *lane_mask, void *stream)
+{
+    Geom g; KCfg k;
+    int rc = check_cfg(cfg, g, k);
+    if (rc) return rc;
+    if (!st || !st->board || !st->dice || !st->done || !st->rng) return EWN_ENULL;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = (size_t)BS * g.cells;
+    BY_NW(g, (k_reset<1><<<GRID(k.N), BS, lds, s>>>(g, k, kstate(st), seeds, lane_mask)),
+          (k_reset<2><<<GRID(k.N), BS, lds, s>>>(g, k, kstate(st), seeds, lane_mask)));
+    return launch_status();
+}
+
+int ewn_predict_mcts(int board_size, int cube_layer, int M, const int8_t *boards, const int8_t *dice, int num_simulations,
+                     int num_env_copies, uint64_t key, const uint32_t *obs_id, int8_t *actions, int32_t *wins, void *stream);
+
+static int mcts_launch(const Geom &g, int M, const int8_t *boards, const int8_t *dice, const uint8_t *active, int total, u64 key,
+                       const u32 *obs_id, int8_t *actions, int32_t *wins, hipStream_t s)
+{
+    const long long threads = (long long)M * 6 * total;
+    if (threads > 0x7fffffffll * BS) return EWN_EINVAL;
+    BY_NW(g, (k_mcts_init<1><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, active, wins)),
+          (k_mcts_init<2><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, active, wins)));
+    BY_NW(g, (k_mcts_rollout<1><<<GRID(threads), BS, 0, s>>>(g, M, total, boards, dice, obs_id, key, wins)),
+          (k_mcts_rollout<2><<<GRID(threads), BS, 0, s>>>(g, M, total, boards, dice, obs_id, key, wins)));
+    BY_NW(g, (k_mcts_pick<1><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, wins, actions)),
+          (k_mcts_pick<2><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, wins, actions)));
+    return launch_status();
+}
+
+int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, const ewn_step_out *out, void *scratch, void *stream)
+{
+    Geom g; KCfg k;
+    int rc = check_cfg(cfg, g, k);
+    if (rc) return rc;
+    if (!st || !st->board || !st->dice || !st->done || !st->rng || !actions || !out) return EWN_ENULL;
+    if (!out->reward || !out->terminated || !out->truncated || !out->info) return EWN_ENULL;
+    if (cfg->shaped && (!st->prev_score || !st->tolerance)) return EWN_ENULL;
+    hipStream_t s = (hipStream_t)stream;
+    KOut ko = { out->reward, out->terminated, out->truncated, out->info, out->terminal_board, out->terminal_dice };
+    KState ks = kstate(st);
+    if (!cfg->shaped) { ks.prev_score = nullptr; ks.tolerance = nullptr; }
+    KScratch sc = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    const size_t lds = (size_t)2 * BS * g.cells;
+    if (cfg->opponent_kind != EWN_OPP_MCTS) {
+        BY_NW(g, (k_step<1, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)),
+              (k_step<2, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)));
+        return launch_status();
+    }
+    if (!scratch) return EWN_ENULL;
+    carve_scratch(g, k, scratch, sc);
+    BY_NW(g, (k_step<1, 1><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)),
+          (k_step<2, 1><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)));
+    rc = launch_status();
+    if (rc) return rc;
+    rc = mcts_launch(g, k.N, sc.cboard, sc.cdice, sc.phase, k.nsim_total, k.key, sc.obs_id, sc.act, sc.wins, s);
+    if (rc) return rc;
+    BY_NW(g, (k_step<1, 2><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)),
+          (k_step<2, 2><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)));
+    return launch_status();
+}
+
+static int query_geom(int S, int L, int M, const void *boards, Geom &g)
+{
+    if (S > EWN_MAX_BOARD && L >= 1 && L < S - 1) return EWN_EUNSUPPORTED;
+    if (!make_geom(S, L, g) || M < 0) return EWN_EINVAL;
+    if (M > 0 && !boards) return EWN_ENULL;
+    return EWN_OK;
+}
+
+int ewn_legal_actions(int board_size, int cube_layer, int M, const int8_t *boards, const int8_t *dice, int player, int8_t *acts,
+                      int8_t *n_acts, int8_t *cube_small, int8_t *cube_large, uint8_t *win, void *stream)
+{
+    Geom g;
+    int rc = query_geom(board_size, cube_layer, M, boards, g);
+    if (rc) return rc;
+    if (player != 1 && player != 2) return EWN_EINVAL; // Player.get_opponent raises ValueError otherwise, constants/player.py:17
+    if (M == 0) return EWN_OK;
+    if (!dice) return EWN_ENULL;
+    hipStream_t s = (hipStream_t)stream;
+    BY_NW(g, (k_legal<1><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, player, acts, n_acts, cube_small, cube_large, win)),
+          (k_legal<2><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, player, acts, n_acts, cube_small, cube_large, win)));
+    return launch_status();
+}
+
+int ewn_evaluate(int board_size, int cube_layer, int M, const int8_t *boards, int heuristic, double *out, void *stream)
+{
+    Geom g;
+    int rc = query_geom(board_size, cube_layer, M, boards, g);
+    if (rc) return rc;
+    if (heuristic < 0 || heuristic > EWN_H_ATTK) return EWN_EUNSUPPORTED;
+    if (M == 0) return EWN_OK;
+    if (!out) return EWN_ENULL;
+    hipStream_t s = (hipStream_t)stream;
+    BY_NW(g, (k_evaluate<1><<<GRID(M), BS, 0, s>>>(g, M, boards, heuristic, out)),
+          (k_evaluate<2><<<GRID(M), BS, 0, s>>>(g, M, boards, heuristic, out)));
+    return launch_status();
+}
+
+int ewn_predict_minimax(int board_size, int cube_layer, int M, const int8_t *boards, const int8_t *dice, int max_depth,
+                        int heuristic, int8_t *actions, double *values, void *stream)
+{
+    Geom g;
+    int rc = query_geom(board_size, cube_layer, M, boards, g);
+    if (rc) return rc;
+    if (max_depth < 1) return EWN_EINVAL;
+    if (max_depth > EWN_MAX_DEPTH || heuristic < 0 || heuristic > EWN_H_ATTK || g.CN < 6) return EWN_EUNSUPPORTED;
+    if (M == 0) return EWN_OK;
+    if (!dice || !actions) return EWN_ENULL;
+    hipStream_t s = (hipStream_t)stream;
+    BY_NW(g, launch_minimax<1>(g, M, boards, dice, max_depth, heuristic, actions, values, s),
+          launch_minimax<2>(g, M, boards, dice, max_depth, heuristic, actions, values, s));
+    return launch_status();
+}
+
+int ewn_predict_random(int board_size, int cube_layer, int M, const int8_t *boards, const int8_t *dice, uint64_t key,
+                       uint32_t step, int32_t lane_offset, int8_t *actions, void *stream)
+{
+    Geom g;
+    int rc = query_geom(board_size, cube_layer, M, boards, g);
+    if (rc) return rc;
+    if (M == 0) return EWN_OK;
+    if (!dice || !actions) return EWN_ENULL;
+    hipStream_t s = (hipStream_t)stream;
+    BY_NW(g, (k_predict_random<1><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, key, step, lane_offset, actions)),
+          (k_predict_random<2><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, key, step, lane_offset, actions)));
+    return launch_status();
+}
+
+int ewn_predict_mcts(int board_size, int cube_layer, int M, const int8_t *boards, const int8_t *dice, int num_simulations,
+                     int num_env_copies, uint64_t key, const uint32_t *obs_id, int8_t *actions, int32_t *wins, void *stream)
+{
+    Geom g;
+    int rc = query_geom(board_size, cube_layer, M, boards, g);
+    if (rc) return rc;
+    if (num_simulations < 1 || num_env_copies < 1) return EWN_EINVAL;
+    if (g.CN < 6) return EWN_EUNSUPPORTED;
+    if (M == 0) return EWN_OK;
+    if (!dice || !actions || !wins) return EWN_ENULL;
+    return mcts_launch(g, M, boards, dice, nullptr, num_simulations * num_env_copies, key, obs_id, actions, wins, (hipStream_t)stream);
+}
+
+} // extern "C"

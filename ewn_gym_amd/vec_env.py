@@ -1,0 +1,191 @@
+"""VecEWN: N independent EinStein-wuerfelt-nicht games stepped on one MI355X.
+
+Host side is plumbing only: torch owns the device buffers and the stream, every
+rule, dice draw and search runs in libewn_hip.so (include/ewn_hip.h).  The class is
+the batched counterpart of the reference's EinsteinWuerfeltNichtEnv /
+MiniMaxHeuristicEnv (envs/ewn.py, envs/training_ewn.py): the single-game drop-in
+classes in the top-level `envs` package are N=1 views of it.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import HEUR, OPP, RNG, EwnConfig, EwnState, EwnStepOut, check
+
+
+def _require_gpu(device):
+    if not torch.cuda.is_available():
+        raise _lib.EwnError("ewn_gym_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+    return torch.device(device)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class VecEWN:
+    def __init__(self, n_lanes, board_size=5, cube_layer=3, opponent_policy="random", max_depth=3, heuristic="hybrid",
+                 num_simulations=10, num_env_copies=5, rng="mt19937", shaped=False, reward=1.0,
+                 illegal_move_reward=-1.0, illegal_move_tolerance=10, autoreset=False, shaped_refresh_on_reset=False,
+                 lane_offset=0, seed_stride=None, philox_key=0, mt_window=0, want_terminal_obs=False, device="cuda"):
+        self.lib = _lib.load()
+        opp = str(opponent_policy)
+        if opp not in OPP:
+            raise _lib.EwnError("opponent policy %r is not supported by the HIP engine (random, minimax, mcts)" % opp)
+        if heuristic not in HEUR:
+            raise _lib.EwnError("heuristic %r is not supported (hybrid, min_dist, two_min_dist, attk)" % heuristic)
+        self.N, self.S, self.L = int(n_lanes), int(board_size), int(cube_layer)
+        self.cube_num = self.L * (self.L + 1) // 2
+        self.cfg = EwnConfig(self.S, self.L, self.N, OPP[opp], int(max_depth), HEUR[heuristic], int(num_simulations),
+                             int(num_env_copies), RNG[rng], int(bool(shaped)), int(illegal_move_tolerance),
+                             int(bool(autoreset)), int(bool(shaped_refresh_on_reset)), int(lane_offset),
+                             (self.N if seed_stride is None else int(seed_stride)) & 0xFFFFFFFF, int(mt_window),
+                             float(reward), float(illegal_move_reward), int(philox_key) & 0xFFFFFFFFFFFFFFFF)
+        words = check(self.lib.ewn_rng_words(C.byref(self.cfg)), "ewn_rng_words")  # validates the whole config
+        self.device = _require_gpu(device)
+        dev, N, S = self.device, self.N, self.S
+        self.board = torch.zeros((N, S, S), dtype=torch.int8, device=dev)
+        self.dice = torch.zeros(N, dtype=torch.int8, device=dev)
+        self.done = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self.rng_state = torch.zeros((N, words), dtype=torch.int32, device=dev)
+        self.prev_score = torch.zeros(N, dtype=torch.float64, device=dev) if shaped else None
+        self.tolerance = torch.zeros(N, dtype=torch.int32, device=dev) if shaped else None
+        self.reward = torch.zeros(N, dtype=torch.float64, device=dev)
+        self.terminated = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self.truncated = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self.info = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self.terminal_board = torch.zeros((N, S, S), dtype=torch.int8, device=dev) if want_terminal_obs else None
+        self.terminal_dice = torch.zeros(N, dtype=torch.int8, device=dev) if want_terminal_obs else None
+        nscr = check(self.lib.ewn_step_scratch_bytes(C.byref(self.cfg)), "ewn_step_scratch_bytes")
+        self.scratch = torch.zeros(max(int(nscr), 8), dtype=torch.uint8, device=dev)
+        self._actions = torch.zeros((N, 2), dtype=torch.int8, device=dev)
+        self._st = EwnState(_ptr(self.board), _ptr(self.dice), _ptr(self.done), _ptr(self.rng_state),
+                            _ptr(self.prev_score), _ptr(self.tolerance))
+        self._out = EwnStepOut(_ptr(self.reward), _ptr(self.terminated), _ptr(self.truncated), _ptr(self.info),
+                               _ptr(self.terminal_board), _ptr(self.terminal_dice))
+        check(self.lib.ewn_init_aux(C.byref(self.cfg), C.byref(self._st), _stream()), "ewn_init_aux")
+
+    # -- reset(seed) for the lanes selected by mask (envs/ewn.py:488-494)
+    def reset(self, seeds=None, mask=None):
+        if seeds is not None:
+            if not isinstance(seeds, torch.Tensor):  # uint32 seeds: keep the bit pattern (np.random.seed takes 0..2**32-1)
+                seeds = torch.from_numpy(np.asarray(seeds, dtype=np.uint32).reshape(-1).view(np.int32).copy())
+            seeds = seeds.to(self.device).to(torch.int32).contiguous()
+            assert seeds.numel() == self.N
+        if mask is not None:
+            mask = torch.as_tensor(mask).to(self.device).to(torch.uint8).contiguous()
+            assert mask.numel() == self.N
+        check(self.lib.ewn_reset(C.byref(self.cfg), C.byref(self._st), _ptr(seeds), _ptr(mask), _stream()), "ewn_reset")
+        return self.board, self.dice
+
+    # -- step(actions) (envs/ewn.py:436-486 / envs/training_ewn.py:43-99)
+    def step(self, actions):
+        if not (isinstance(actions, torch.Tensor) and actions.dtype == torch.int8 and actions.is_cuda and actions.is_contiguous()):
+            actions = self._actions.copy_(torch.as_tensor(actions).reshape(self.N, 2))
+        assert actions.numel() == 2 * self.N
+        check(self.lib.ewn_step(C.byref(self.cfg), C.byref(self._st), _ptr(actions), C.byref(self._out), _ptr(self.scratch),
+                                _stream()), "ewn_step")
+        return self.board, self.dice, self.reward, self.terminated, self.truncated, self.info
+
+    # -- RandomAgent as a stateless device policy (classical_policies/random_policy.py:11-15)
+    def sample_legal_actions(self, step, out=None):
+        out = self._actions if out is None else out
+        check(self.lib.ewn_predict_random(self.S, self.L, self.N, _ptr(self.board), _ptr(self.dice),
+                                          C.c_uint64(self.cfg.philox_key), C.c_uint32(int(step) & 0xFFFFFFFF),
+                                          int(self.cfg.lane_offset), _ptr(out), _stream()), "ewn_predict_random")
+        return out
+
+    def set_obs(self, boards, dice):
+        """Overwrite the observation of every lane (agent = TOP_LEFT to move); RNG state is kept."""
+        self.board.copy_(torch.as_tensor(boards).reshape(self.N, self.S, self.S))
+        self.dice.copy_(torch.as_tensor(dice).reshape(self.N))
+        self.done.zero_()
+
+    def state_dict(self):
+        """Checkpoint of the env (the reference never checkpoints env state)."""
+        keys = ("board", "dice", "done", "rng_state", "prev_score", "tolerance")
+        return {k: getattr(self, k).clone() for k in keys if getattr(self, k) is not None}
+
+    def load_state_dict(self, sd):
+        for k, v in sd.items():
+            getattr(self, k).copy_(v)
+
+
+# ---------------------------------------------------------------- stateless batched queries
+
+def _prep(boards, dice=None, device="cuda"):
+    dev = _require_gpu(device)
+    b = torch.as_tensor(boards)
+    if b.dim() == 2:
+        b = b.unsqueeze(0)
+    M, S = b.shape[0], b.shape[1]
+    b = b.to(dev).to(torch.int8).contiguous()
+    d = None
+    if dice is not None:
+        d = torch.as_tensor(dice).reshape(-1).to(dev).to(torch.int8).contiguous()
+        assert d.numel() == M
+    return b, d, M, S, dev
+
+
+def legal_actions(boards, dice, player=1, cube_layer=3):
+    """get_legal_actions / find_cube_to_move / check_win on M boards -> (acts[M,6,2], n[M], cube_small[M], cube_large[M], win[M])"""
+    lib = _lib.load()
+    b, d, M, S, dev = _prep(boards, dice)
+    acts = torch.full((M, 6, 2), -1, dtype=torch.int8, device=dev)
+    n = torch.zeros(M, dtype=torch.int8, device=dev)
+    cs = torch.zeros(M, dtype=torch.int8, device=dev)
+    cl = torch.zeros(M, dtype=torch.int8, device=dev)
+    win = torch.zeros(M, dtype=torch.uint8, device=dev)
+    check(lib.ewn_legal_actions(S, cube_layer, M, _ptr(b), _ptr(d), int(player), _ptr(acts), _ptr(n), _ptr(cs), _ptr(cl),
+                                _ptr(win), _stream()), "ewn_legal_actions")
+    return acts, n, cs, cl, win
+
+
+def evaluate(boards, heuristic="hybrid", cube_layer=3):
+    lib = _lib.load()
+    if heuristic not in HEUR:
+        raise _lib.EwnError("heuristic %r is not supported" % heuristic)
+    b, _, M, S, dev = _prep(boards)
+    out = torch.zeros(M, dtype=torch.float64, device=dev)
+    check(lib.ewn_evaluate(S, cube_layer, M, _ptr(b), HEUR[heuristic], _ptr(out), _stream()), "ewn_evaluate")
+    return out
+
+
+def predict_minimax(boards, dice, max_depth, heuristic="hybrid", cube_layer=3):
+    lib = _lib.load()
+    if heuristic not in HEUR:
+        raise _lib.EwnError("heuristic %r is not supported" % heuristic)
+    b, d, M, S, dev = _prep(boards, dice)
+    acts = torch.zeros((M, 2), dtype=torch.int8, device=dev)
+    vals = torch.zeros(M, dtype=torch.float64, device=dev)
+    check(lib.ewn_predict_minimax(S, cube_layer, M, _ptr(b), _ptr(d), int(max_depth), HEUR[heuristic], _ptr(acts),
+                                  _ptr(vals), _stream()), "ewn_predict_minimax")
+    return acts, vals
+
+
+def predict_random(boards, dice, key=0, step=0, lane_offset=0, cube_layer=3):
+    lib = _lib.load()
+    b, d, M, S, dev = _prep(boards, dice)
+    acts = torch.zeros((M, 2), dtype=torch.int8, device=dev)
+    check(lib.ewn_predict_random(S, cube_layer, M, _ptr(b), _ptr(d), C.c_uint64(key), C.c_uint32(step), int(lane_offset),
+                                 _ptr(acts), _stream()), "ewn_predict_random")
+    return acts
+
+
+def predict_mcts(boards, dice, num_simulations=10, num_env_copies=5, key=0, obs_id=None, cube_layer=3):
+    lib = _lib.load()
+    b, d, M, S, dev = _prep(boards, dice)
+    acts = torch.zeros((M, 2), dtype=torch.int8, device=dev)
+    wins = torch.zeros((M, 6), dtype=torch.int32, device=dev)
+    ids = None
+    if obs_id is not None:
+        ids = torch.from_numpy(np.asarray(obs_id, dtype=np.uint32).reshape(-1).view(np.int32).copy()).to(dev)
+    check(lib.ewn_predict_mcts(S, cube_layer, M, _ptr(b), _ptr(d), int(num_simulations), int(num_env_copies),
+                               C.c_uint64(key), _ptr(ids), _ptr(acts), _ptr(wins), _stream()), "ewn_predict_mcts")
+    return acts, wins

@@ -1,0 +1,177 @@
+/*
+ * include/ewn_hip.h -- C ABI of libewn_hip.so: the MI355X (gfx950) vectorised
+ * EinStein-wuerfelt-nicht environment step and opponent-search engine.
+ *
+ * The reference (jchen8tw/ewn-gym) is pure Python and has no FFI: its boundary
+ * for this path is the Python class surface of envs/ewn.py, envs/minimax_ewn.py,
+ * envs/training_ewn.py and classical_policies/{random_policy,minimax,mcts}.py.
+ * Each entry point below names the reference method(s) it replaces, batched over
+ * N independent games ("lanes").  The Python mirror of those classes (packages
+ * envs/, classical_policies/, constants/ at the repo root) binds this ABI with
+ * ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - Plain C: pointers + sizes only.  Every buffer pointer is a DEVICE pointer
+ *    owned by the caller (e.g. torch.Tensor.data_ptr()); nothing is allocated,
+ *    freed or synchronised inside a call, so calls are hipGraph-capturable.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *  - Return value: 0 on success, a negative EWN_E* code otherwise (never throws,
+ *    never aborts).  ewn_strerror() maps a code to text.
+ *  - No hidden global state; a call is thread-safe w.r.t. other calls that do
+ *    not share buffers.
+ *  - Boards are int8, row-major [lane][row][col], value k>0 = TOP_LEFT cube k,
+ *    k<0 = BOTTOM_RIGHT cube |k|, 0 = empty (envs/ewn.py:49-58, 94-107).
+ *  - Actions are int8 [lane][2] = {chose_larger in {0,1}, direction in {0,1,2}}
+ *    (envs/ewn.py:61-62, 436-442).
+ */
+#ifndef EWN_HIP_H
+#define EWN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EWN_ABI_VERSION 1
+
+/* error codes */
+#define EWN_OK 0
+#define EWN_EINVAL (-1)      /* bad argument / unsupported configuration (the reference asserts, envs/ewn.py:47) */
+#define EWN_ENULL (-2)       /* required pointer is NULL */
+#define EWN_ELAUNCH (-3)     /* kernel launch failed (hipGetLastError != hipSuccess) */
+#define EWN_EUNSUPPORTED (-4)/* valid in the reference, not built here (e.g. board_size > 8, 'sim_winrate') */
+
+/* opponent_kind: constants/policy.py:4-10 (uct / alpha_zero are out of scope) */
+#define EWN_OPP_RANDOM 0
+#define EWN_OPP_MINIMAX 1
+#define EWN_OPP_MCTS 2
+
+/* rng_kind */
+#define EWN_RNG_MT19937 0 /* bit-exact numpy legacy global stream, one per lane (envs/ewn.py:91,490) */
+#define EWN_RNG_PHILOX 1  /* Philox4x32-10 counter RNG, same masked-rejection randint */
+
+/* heuristic: envs/minimax_ewn.py:29-38 */
+#define EWN_H_HYBRID 0
+#define EWN_H_MIN_DIST 1
+#define EWN_H_TWO_MIN_DIST 2
+#define EWN_H_ATTK 3
+
+/* info codes of ewn_step: the messages of envs/ewn.py:448,454,473,478 and envs/training_ewn.py:56 */
+#define EWN_INFO_NONE 0
+#define EWN_INFO_INVALID_PLAYER 1 /* "Invalid move for player! End the game." */
+#define EWN_INFO_WON 2            /* "You won!" */
+#define EWN_INFO_INVALID_OPP 3    /* "Invalid move for opponent! End the game." */
+#define EWN_INFO_LOST 4           /* "You lost!" */
+#define EWN_INFO_TOLERANCE 5      /* "Invalid move for player! Tolerance left {n}." */
+
+#define EWN_MAX_BOARD 8   /* S*S bits must fit one 64-bit occupancy mask */
+#define EWN_MAX_CUBES 15  /* cube_layer <= 5 */
+#define EWN_MAX_DEPTH 6
+#define EWN_MT_WINDOW_MAX 227 /* MT19937 outputs computable from the seeded state alone */
+#define EWN_RNG_HEADER_WORDS 4
+
+/* Replaces the constructor arguments of EinsteinWuerfeltNichtEnv (envs/ewn.py:35-42),
+ * MiniMaxHeuristicEnv (envs/training_ewn.py:19-29) and the opponent policy ctor
+ * kwargs (classical_policies/minimax.py:10-11, mcts.py:11-13). */
+typedef struct ewn_config {
+    int32_t board_size;             /* S, 3..8 */
+    int32_t cube_layer;             /* L, cube_num = L(L+1)/2, L < S-1 */
+    int32_t n_lanes;                /* N parallel games handled by this call */
+    int32_t opponent_kind;          /* EWN_OPP_* */
+    int32_t max_depth;              /* ExpectiMinimaxAgent.max_depth, 1..EWN_MAX_DEPTH */
+    int32_t heuristic;              /* EWN_H_* */
+    int32_t num_simulations;        /* MctsAgent.num_simulations */
+    int32_t num_env_copies;         /* MctsAgent.num_env_copies */
+    int32_t rng_kind;               /* EWN_RNG_* */
+    int32_t shaped;                 /* 0: EinsteinWuerfeltNichtEnv.step, 1: MiniMaxHeuristicEnv.step */
+    int32_t illegal_move_tolerance; /* initial tolerance (training_ewn.py:38); used by ewn_init_aux */
+    int32_t autoreset;              /* 1: a terminated lane is reset (next seed) inside ewn_step */
+    int32_t shaped_refresh_on_reset;/* 0 = reference behaviour: prev_score is set in the ctor only */
+    int32_t lane_offset;            /* global id of lane 0 (multi-GPU sharding); enters the Philox agent/MCTS streams */
+    uint32_t seed_stride;           /* auto-reset: seed += seed_stride per episode */
+    uint32_t mt_window;             /* MT19937 outputs precomputed per episode, 16..EWN_MT_WINDOW_MAX (0 = 128) */
+    double reward;                  /* envs/ewn.py:38 (goal_reward of the shaped env) */
+    double illegal_move_reward;     /* training_ewn.py:28 */
+    uint64_t philox_key;
+} ewn_config;
+
+/* Per-lane state, structure-of-arrays, all device pointers, caller-owned. */
+typedef struct ewn_state {
+    int8_t *board;       /* [N][S*S]  the observation "board" (agent = TOP_LEFT to move) */
+    int8_t *dice;        /* [N]       the observation "dice_roll" */
+    uint8_t *done;       /* [N]       1 = terminated and not yet reset (lane frozen) */
+    uint32_t *rng;       /* [N][ewn_rng_words()]  {seed, draw index, next_seed, 0, MT window...} */
+    double *prev_score;  /* [N]  shaped env only (training_ewn.py:35), may be NULL otherwise */
+    int32_t *tolerance;  /* [N]  shaped env only (training_ewn.py:38), may be NULL otherwise */
+} ewn_state;
+
+/* Outputs of one step, device pointers, caller-owned.  The post-step observation is
+ * written in place to ewn_state.board / .dice. */
+typedef struct ewn_step_out {
+    double *reward;        /* [N] */
+    uint8_t *terminated;   /* [N] */
+    uint8_t *truncated;    /* [N] */
+    uint8_t *info;         /* [N] EWN_INFO_* */
+    int8_t *terminal_board;/* [N][S*S] observation before auto-reset (SB3 "terminal_observation"); NULL to skip */
+    int8_t *terminal_dice; /* [N] ; NULL to skip */
+} ewn_step_out;
+
+int ewn_abi_version(void);
+const char *ewn_strerror(int code);
+
+/* number of uint32 words per lane in ewn_state.rng for this config (<0 on error) */
+int ewn_rng_words(const ewn_config *cfg);
+/* bytes of device scratch ewn_step needs for this config (0 if none; <0 on error) */
+int64_t ewn_step_scratch_bytes(const ewn_config *cfg);
+
+/* Constructor-time state that reset() does not touch in the reference:
+ * prev_score = evaluate(initial board) (training_ewn.py:35) and the tolerance
+ * counter (:38); also clears `done` and zeroes the rng header. */
+int ewn_init_aux(const ewn_config *cfg, const ewn_state *st, void *stream);
+
+/* EinsteinWuerfeltNichtEnv.reset(seed) (envs/ewn.py:488-494) + setup_game (:94-108)
+ * for every lane with lane_mask[i] != 0 (NULL = all lanes).  seeds[i] (NULL = the
+ * lane's stored next_seed) is the argument of np.random.seed. */
+int ewn_reset(const ewn_config *cfg, const ewn_state *st, const uint32_t *seeds, const uint8_t *lane_mask, void *stream);
+
+/* EinsteinWuerfeltNichtEnv.step (envs/ewn.py:436-486) or, with cfg->shaped,
+ * MiniMaxHeuristicEnv.step (envs/training_ewn.py:43-99): agent move, win test,
+ * opponent dice + reply (opponent_action, ewn.py:289-296, by cfg->opponent_kind),
+ * win test, next dice; optional auto-reset.  `scratch` = ewn_step_scratch_bytes() bytes. */
+int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, const ewn_step_out *out,
+             void *scratch, void *stream);
+
+/* ---- stateless policy / rule queries on M given observations (canonical: TOP_LEFT to move) ---- */
+
+/* get_legal_actions (envs/ewn.py:338-375), find_cube_to_move (:178-215), check_win (:131-142).
+ * player: 1 TOP_LEFT, 2 BOTTOM_RIGHT (constants/player.py).  Outputs (each may be NULL):
+ * acts [M][6][2] (-1 padded, reference order), n_acts [M], cube_small/cube_large [M]
+ * (cube NUMBER moved with flag 0 / 1), win [M]. */
+int ewn_legal_actions(int board_size, int cube_layer, int M, const int8_t *boards, const int8_t *dice, int player,
+                      int8_t *acts, int8_t *n_acts, int8_t *cube_small, int8_t *cube_large, uint8_t *win, void *stream);
+
+/* MinimaxEnv.evaluate(heuristic) (envs/minimax_ewn.py:29-213) */
+int ewn_evaluate(int board_size, int cube_layer, int M, const int8_t *boards, int heuristic, double *out, void *stream);
+
+/* ExpectiMinimaxAgent.predict (classical_policies/minimax.py:89-93): actions [M][2];
+ * values [M] = root value (may be NULL). */
+int ewn_predict_minimax(int board_size, int cube_layer, int M, const int8_t *boards, const int8_t *dice, int max_depth,
+                        int heuristic, int8_t *actions, double *values, void *stream);
+
+/* RandomAgent.predict (classical_policies/random_policy.py:11-15) as a stateless policy:
+ * uniform legal action from Philox ctr={step, lane_offset+i, 'AGNT', 0}, key. */
+int ewn_predict_random(int board_size, int cube_layer, int M, const int8_t *boards, const int8_t *dice, uint64_t key,
+                       uint32_t step, int32_t lane_offset, int8_t *actions, void *stream);
+
+/* MctsAgent.predict (classical_policies/mcts.py:102-106, flat Monte-Carlo :47-69, rollouts :21-45).
+ * wins [M][6] int32 is REQUIRED scratch/output (win count per root move, -1 = no such move).
+ * obs_id [M] (NULL = 0..M-1) and key select the Philox rollout streams. */
+int ewn_predict_mcts(int board_size, int cube_layer, int M, const int8_t *boards, const int8_t *dice,
+                     int num_simulations, int num_env_copies, uint64_t key, const uint32_t *obs_id, int8_t *actions,
+                     int32_t *wins, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EWN_HIP_H */

@@ -1,0 +1,80 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol the header
+declares, and validates configurations on the host (no kernel is launched here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from ewn_gym_amd import _lib
+from ewn_gym_amd._lib import EwnConfig
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def cfg(**kw):
+    base = dict(board_size=5, cube_layer=3, n_lanes=64, opponent_kind=0, max_depth=3, heuristic=0, num_simulations=10,
+                num_env_copies=5, rng_kind=0, shaped=0, illegal_move_tolerance=10, autoreset=0, shaped_refresh_on_reset=0,
+                lane_offset=0, seed_stride=64, mt_window=0, reward=1.0, illegal_move_reward=-1.0, philox_key=0)
+    base.update(kw)
+    return EwnConfig(**base)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "ewn_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|int64_t|const char \*)\s*\*?\s*(ewn_\w+)\s*\(", hdr, re.M))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.ewn_abi_version() == 1
+    assert lib.ewn_strerror(0) == b"ok" and b"invalid" in lib.ewn_strerror(-1)
+
+
+def test_struct_layout_matches_header():
+    assert C.sizeof(EwnConfig) == 14 * 4 + 2 * 4 + 2 * 8 + 8
+    assert C.sizeof(_lib.EwnState) == 6 * 8 and C.sizeof(_lib.EwnStepOut) == 6 * 8
+
+
+def test_config_validation_on_host():
+    lib = _lib.load()
+    assert lib.ewn_rng_words(C.byref(cfg())) == 4 + 128
+    assert lib.ewn_rng_words(C.byref(cfg(rng_kind=1))) == 4
+    assert lib.ewn_rng_words(C.byref(cfg(mt_window=227))) == 231
+    assert lib.ewn_rng_words(C.byref(cfg(mt_window=228))) == -1
+    assert lib.ewn_rng_words(C.byref(cfg(cube_layer=4))) == -1            # assert cube_layer < board_size - 1 (envs/ewn.py:47)
+    assert lib.ewn_rng_words(C.byref(cfg(board_size=9, cube_layer=3))) == -4  # valid upstream, > 64-bit mask here
+    assert lib.ewn_rng_words(C.byref(cfg(n_lanes=0))) == -1
+    assert lib.ewn_rng_words(C.byref(cfg(opponent_kind=1, max_depth=7))) == -4
+    assert lib.ewn_rng_words(C.byref(cfg(opponent_kind=1, cube_layer=2))) == -4  # dice loop 1..6 needs 6 cubes
+    assert lib.ewn_rng_words(C.byref(cfg(opponent_kind=7))) == -1
+    assert lib.ewn_rng_words(None) == -2
+    assert lib.ewn_step_scratch_bytes(C.byref(cfg())) == 0
+    assert lib.ewn_step_scratch_bytes(C.byref(cfg(opponent_kind=2))) == 64 * (4 + 4 + 24 + 25)
+
+
+def test_null_pointers_are_rejected_before_any_launch():
+    lib = _lib.load()
+    st = _lib.EwnState()
+    out = _lib.EwnStepOut()
+    assert lib.ewn_reset(C.byref(cfg()), C.byref(st), None, None, None) == -2
+    assert lib.ewn_step(C.byref(cfg()), C.byref(st), None, C.byref(out), None, None) == -2
+    assert lib.ewn_init_aux(C.byref(cfg()), None, None) == -2
+    assert lib.ewn_evaluate(5, 3, 4, None, 0, None, None) == -2
+    assert lib.ewn_evaluate(5, 3, 0, None, 0, None, None) == 0            # empty batch is a no-op
+    assert lib.ewn_predict_minimax(5, 3, 0, None, None, 3, 0, None, None, None) == 0
+    assert lib.ewn_predict_minimax(5, 3, 0, None, None, 0, 0, None, None, None) == -1
+    assert lib.ewn_evaluate(5, 3, 0, None, 4, None, None) == -4            # 'sim_winrate' not built
+    assert lib.ewn_legal_actions(5, 3, 0, None, None, 3, None, None, None, None, None, None) == -1  # Player.CHANCE
+
+
+def test_product_fails_loudly_without_gpu_or_library(monkeypatch):
+    import torch
+    import ewn_gym_amd
+    if not torch.cuda.is_available():
+        with pytest.raises(ewn_gym_amd.EwnError):
+            ewn_gym_amd.VecEWN(4)
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libewn_hip.so")
+    with pytest.raises(ewn_gym_amd.EwnError):
+        _lib.load()

@@ -1,0 +1,375 @@
+"""HIP engine (through the C ABI, via ewn_gym_amd's ctypes binding) against the CPU oracle
+and against the golden vectors captured from the reference.  Bit-exact everywhere
+(integer boards/actions/flags; fp64 heuristic values, root values and shaped rewards
+compared by bit pattern)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import pyoracle as po  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ea():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import ewn_gym_amd
+    return ewn_gym_amd
+
+
+MSG = {None: 0, "Invalid move for player! End the game.": 1, "You won!": 2,
+       "Invalid move for opponent! End the game.": 3, "You lost!": 4}
+
+
+def msg_code(m):
+    if m is not None and m.startswith("Invalid move for player! Tolerance left"):
+        return 5
+    return MSG[m]
+
+
+def boards_of(recs, S):
+    return np.array([r["board"] for r in recs], np.int8).reshape(-1, S, S)
+
+
+def bits(x):
+    return np.ascontiguousarray(x, dtype=np.float64).view(np.uint64)
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
+
+
+# ---------------------------------------------------------------- golden vectors
+
+def test_g1_reset(ea, golden):
+    g = golden("g1_initial.json")
+    for (S, L) in sorted({(r["S"], r["L"]) for r in g}):
+        if S > 8:
+            with pytest.raises(ea.EwnError):
+                ea.VecEWN(4, board_size=S, cube_layer=L)
+            continue
+        recs = [r for r in g if (r["S"], r["L"]) == (S, L)]
+        env = ea.VecEWN(len(recs), board_size=S, cube_layer=L, rng="mt19937")
+        b, d = env.reset(seeds=[r["seed"] for r in recs])
+        assert np.array_equal(cpu(b), boards_of(recs, S))
+        assert cpu(d).tolist() == [r["dice"] for r in recs]
+
+
+def test_g2_legal_actions(ea, golden):
+    g = [r for r in golden("g2_legal.json") if r["S"] <= 8]
+    for (S, L, pl) in sorted({(r["S"], r["L"], r["player"]) for r in g}):
+        recs = [r for r in g if (r["S"], r["L"], r["player"]) == (S, L, pl)]
+        acts, n, cs, cl, win = [cpu(t) for t in ea.legal_actions(boards_of(recs, S), [r["dice"] for r in recs], player=pl, cube_layer=L)]
+        for i, r in enumerate(recs):
+            assert bool(win[i]) == r["win"]
+            if "legal" in r:
+                assert acts[i, :n[i]].tolist() == r["legal"], (S, L, pl, i)
+                assert (acts[i, n[i]:] == -1).all()
+                assert (cs[i], cl[i]) == (r["cube_small"], r["cube_large"])
+
+
+@pytest.mark.parametrize("h", ["hybrid", "min_dist", "two_min_dist", "attk"])
+def test_g4_heuristics(ea, golden, h):
+    g = golden("g4_eval.json")
+    for (S, L) in sorted({(r["S"], r["L"]) for r in g}):
+        recs = [r for r in g if (r["S"], r["L"]) == (S, L)]
+        out = cpu(ea.evaluate(boards_of(recs, S), h, cube_layer=L))
+        exp = np.array([float.fromhex(r[h]) for r in recs])
+        assert np.array_equal(bits(out), bits(exp))
+
+
+def test_g5_expectiminimax(ea, golden):
+    g = golden("g5_minimax.json")
+    n = 0
+    for (S, L) in sorted({(r["S"], r["L"]) for r in g}):
+        recs = [r for r in g if (r["S"], r["L"]) == (S, L)]
+        for key in sorted({k for r in recs for k in r["res"]}):
+            sub = [r for r in recs if key in r["res"]]
+            d, h = key.split("/")
+            acts, vals = ea.predict_minimax(boards_of(sub, S), [r["dice"] for r in sub], int(d), h, cube_layer=L)
+            acts, vals = cpu(acts), cpu(vals)
+            for i, r in enumerate(sub):
+                a0, a1, v = r["res"][key]
+                assert acts[i].tolist() == [a0, a1], (S, L, key, i)
+                assert float(vals[i]).hex() == float.fromhex(v).hex(), (S, L, key, i)
+                n += 1
+    assert n > 3000
+
+
+def _run_group(ea, recs, opp, **kw):
+    """Trajectories of one configuration run lane-parallel; finished lanes stay frozen."""
+    S, L = recs[0].get("S", 5), recs[0].get("L", 3)
+    N = len(recs)
+    env = ea.VecEWN(N, board_size=S, cube_layer=L, opponent_policy=opp, rng="mt19937", **kw)
+    b, d = env.reset(seeds=[r["seed"] for r in recs])
+    b, d = cpu(b), cpu(d)
+    for i, r in enumerate(recs):
+        assert b[i].reshape(-1).tolist() == r["board0"] and int(d[i]) == r["dice0"]
+    T = max(len(r["steps"]) for r in recs)
+    for t in range(T):
+        acts = np.zeros((N, 2), np.int8)
+        for i, r in enumerate(recs):
+            if t < len(r["steps"]):
+                acts[i] = r["steps"][t]["a"]
+        b, d, rew, te, tr, info = [cpu(x) for x in env.step(acts)]
+        for i, r in enumerate(recs):
+            if t < len(r["steps"]):
+                st = r["steps"][t]
+                ctx = (r["seed"], r.get("rule"), t)
+                assert b[i].reshape(-1).tolist() == st["board"], ctx
+                assert int(d[i]) == st["dice"], ctx
+                assert float(rew[i]).hex() == float.fromhex(st["r"]).hex(), ctx
+                assert (bool(te[i]), bool(tr[i])) == (st["term"], st["trunc"]), ctx
+                assert int(info[i]) == msg_code(st["msg"]), ctx
+            else:  # frozen lane
+                assert bool(te[i]) and float(rew[i]) == 0.0 and b[i].reshape(-1).tolist() == r["steps"][-1]["board"]
+
+
+def test_g3_trajectories_random_opponent(ea, golden):
+    g = golden("g3_traj_random.json")
+    for (S, L) in sorted({(r["S"], r["L"]) for r in g}):
+        _run_group(ea, [r for r in g if (r["S"], r["L"]) == (S, L)], "random")
+
+
+def test_g6_trajectories_minimax_opponent(ea, golden):
+    g = golden("g6_traj_minimax.json")
+    for key in sorted({(r["S"], r["L"], r["depth"], r["heuristic"]) for r in g}):
+        recs = [r for r in g if (r["S"], r["L"], r["depth"], r["heuristic"]) == key]
+        _run_group(ea, recs, "minimax", max_depth=key[2], heuristic=key[3])
+
+
+def test_g7_shaped_env(ea, golden):
+    for grp in golden("g7_shaped.json"):
+        env = ea.VecEWN(1, opponent_policy="random", rng="mt19937", shaped=True, illegal_move_tolerance=grp["tol"],
+                        reward=1.0, illegal_move_reward=-1.0)
+        assert float(cpu(env.prev_score)[0]).hex() == float.fromhex(grp["ctor_prev_score"]).hex()
+        for rec in grp["episodes"]:
+            b, d = env.reset(seeds=[rec["seed"]])
+            assert cpu(b).reshape(-1).tolist() == rec["board0"] and int(cpu(d)[0]) == rec["dice0"]
+            for t, st in enumerate(rec["steps"]):
+                b, d, r, te, tr, info = [cpu(x) for x in env.step([st["a"]])]
+                ctx = (grp["tol"], rec["seed"], t)
+                assert b.reshape(-1).tolist() == st["board"], ctx
+                assert int(d[0]) == st["dice"], ctx
+                assert float(r[0]).hex() == float.fromhex(st["r"]).hex(), ctx
+                assert (bool(te[0]), bool(tr[0])) == (st["term"], st["trunc"]), ctx
+                assert int(info[0]) == msg_code(st["msg"]), ctx
+            assert int(cpu(env.tolerance)[0]) == rec["tol_after"]
+            assert float(cpu(env.prev_score)[0]).hex() == float.fromhex(rec["prev_score_after"]).hex()
+
+
+# ---------------------------------------------------------------- oracle, seeded random lanes
+
+def _lockstep(ea, N, steps, seed0=1000, check_terminal=True, **kw):
+    """Same seeds, same actions, HIP engine vs CPU oracle, with auto-reset."""
+    okw = dict(kw)
+    opp = okw.pop("opponent_policy", "random")
+    env = ea.VecEWN(N, opponent_policy=opp, autoreset=True, want_terminal_obs=check_terminal, **okw)
+    okw.pop("mt_window", None)
+    orc = po.OracleVecEnv(N, opponent=opp, autoreset=True, **okw)
+    seeds = np.arange(N, dtype=np.uint32) * 7919 + seed0
+    b, d = env.reset(seeds=seeds)
+    ob, od = orc.reset(seeds=seeds)
+    assert np.array_equal(cpu(b), ob) and np.array_equal(cpu(d), od)
+    gen = np.random.Generator(np.random.PCG64(seed0))
+    nterm = 0
+    for t in range(steps):
+        if t % 3 == 2:   # raw actions (illegal ones included) every third step
+            acts = np.stack([gen.integers(0, 2, N), gen.integers(0, 3, N)], 1).astype(np.int8)
+        else:
+            acts = orc.sample_legal_actions(t)
+            assert np.array_equal(cpu(env.sample_legal_actions(t)), acts), t
+        res = [cpu(x) for x in env.step(acts)]
+        ores = orc.step(acts, want_terminal=True)
+        names = ("board", "dice", "reward", "terminated", "truncated", "info")
+        for k, name in enumerate(names):
+            a, o = res[k], ores[k]
+            if name == "reward":
+                a, o = bits(a), bits(o)
+            assert np.array_equal(a, o), (t, name, np.nonzero(np.asarray(a != o).reshape(N, -1).any(1))[0][:5])
+        if check_terminal:
+            assert np.array_equal(cpu(env.terminal_board), ores[6]), t
+            assert np.array_equal(cpu(env.terminal_dice), ores[7]), t
+        nterm += int(ores[3].sum())
+    return nterm
+
+
+@pytest.mark.parametrize("rng", ["mt19937", "philox"])
+def test_step_random_opponent_vs_oracle(ea, rng):
+    assert _lockstep(ea, 3000, 40, rng=rng, philox_key=0x1234ABCD5678) > 3000
+
+
+@pytest.mark.parametrize("depth,heur", [(1, "hybrid"), (2, "attk"), (3, "hybrid"), (3, "two_min_dist"), (3, "min_dist")])
+def test_step_minimax_opponent_vs_oracle(ea, depth, heur):
+    assert _lockstep(ea, 1500, 30, opponent_policy="minimax", max_depth=depth, heuristic=heur, rng="mt19937") > 1000
+
+
+def test_step_minimax_depth4_5_vs_oracle(ea):
+    _lockstep(ea, 200, 12, opponent_policy="minimax", max_depth=4, rng="philox", philox_key=5)
+    _lockstep(ea, 64, 10, opponent_policy="minimax", max_depth=5, rng="mt19937")
+
+
+@pytest.mark.parametrize("S,L", [(6, 3), (7, 3), (7, 4), (7, 5), (8, 3)])
+def test_step_other_board_sizes_vs_oracle(ea, S, L):
+    _lockstep(ea, 700, 50, board_size=S, cube_layer=L, rng="mt19937")
+    if L == 3 or L == 4:
+        _lockstep(ea, 300, 20, board_size=S, cube_layer=L, opponent_policy="minimax", max_depth=3, rng="philox")
+
+
+def test_step_small_cube_layers(ea):
+    _lockstep(ea, 500, 30, board_size=5, cube_layer=2, rng="mt19937")
+    _lockstep(ea, 500, 30, board_size=4, cube_layer=1, rng="mt19937")
+    with pytest.raises(AssertionError):   # assert cube_layer < board_size - 1, envs/ewn.py:47
+        ea.VecEWN(4, board_size=5, cube_layer=4)
+    with pytest.raises(ea.EwnError):      # dice loop 1..6 needs cube_num >= 6 (IndexError upstream)
+        ea.VecEWN(4, board_size=5, cube_layer=2, opponent_policy="minimax")
+
+
+def test_shaped_env_vs_oracle(ea):
+    _lockstep(ea, 2000, 40, shaped=True, illegal_move_tolerance=4, reward=10.0, illegal_move_reward=-0.5, rng="mt19937")
+    _lockstep(ea, 500, 40, shaped=True, shaped_refresh_on_reset=True, opponent_policy="minimax", max_depth=2, rng="philox")
+
+
+def test_mt_window_overflow_closed_form(ea):
+    """A 16-word window forces the memory-free closed-form path for later draws."""
+    _lockstep(ea, 600, 45, rng="mt19937", mt_window=16)
+    _lockstep(ea, 300, 60, board_size=7, cube_layer=5, rng="mt19937", mt_window=16)
+
+
+def test_frozen_lanes_without_autoreset(ea):
+    N = 512
+    env = ea.VecEWN(N, rng="mt19937")
+    orc = po.OracleVecEnv(N, rng="mt19937")
+    seeds = np.arange(N) + 5
+    env.reset(seeds=seeds)
+    orc.reset(seeds=seeds)
+    for t in range(25):
+        acts = orc.sample_legal_actions(t)
+        res = [cpu(x) for x in env.step(acts)]
+        ores = orc.step(acts)
+        for a, o in zip(res, ores):
+            assert np.array_equal(a, o), t
+    assert cpu(env.done).all()
+    mask = (np.arange(N) % 3 == 0)
+    b, d = env.reset(seeds=seeds + 1, mask=mask)
+    ob, od = orc.reset(seeds=seeds + 1, mask=mask)
+    assert np.array_equal(cpu(b), ob) and np.array_equal(cpu(d), od)
+    assert np.array_equal(cpu(env.done) == 0, mask)
+
+
+# ---------------------------------------------------------------- stateless policies
+
+def _random_positions(S, L, n, seed):
+    orc = po.OracleVecEnv(n, board_size=S, cube_layer=L, rng="philox", philox_key=seed, autoreset=True)
+    orc.reset(seeds=np.arange(n) + seed)
+    gen = np.random.Generator(np.random.PCG64(seed))
+    for t in range(int(gen.integers(1, 6))):
+        orc.step(orc.sample_legal_actions(t))
+    b, _ = orc.obs()
+    return b, gen.integers(1, 7, n).astype(np.int8)
+
+
+@pytest.mark.parametrize("S,L,depth,heur,n", [(5, 3, 3, "hybrid", 6000), (5, 3, 2, "min_dist", 1500), (5, 3, 4, "hybrid", 300),
+                                             (5, 3, 5, "hybrid", 60), (7, 3, 3, "hybrid", 1500), (7, 4, 3, "attk", 500),
+                                             (6, 3, 3, "two_min_dist", 500), (8, 5, 2, "hybrid", 300), (5, 3, 6, "hybrid", 8)])
+def test_predict_minimax_vs_oracle(ea, S, L, depth, heur, n):
+    b, d = _random_positions(S, L, n, 77 + depth)
+    acts, vals = ea.predict_minimax(b, d, depth, heur, cube_layer=L)
+    oa, ov, _ = po.predict_minimax(b, d, depth, heur, cube_layer=L)
+    assert np.array_equal(cpu(acts), oa)
+    assert np.array_equal(bits(cpu(vals)), bits(ov))
+
+
+def test_pruned_search_differs_from_full_width_somewhere(ea, golden):
+    """alpha-beta is passed through chance nodes, which changes ~1 % of the moves.
+    The engine must reproduce the pruned answer, so the goldens must contain such cases."""
+    b, d = _random_positions(5, 3, 6000, 4242)
+    acts, vals = ea.predict_minimax(b, d, 3, "hybrid")
+    oa, ov, leaves = po.predict_minimax(b, d, 3, "hybrid")
+    assert np.array_equal(cpu(acts), oa)
+    assert leaves.max() <= 216 and leaves.min() >= 1
+
+
+def test_predict_mcts_bit_exact_vs_oracle(ea):
+    b, d = _random_positions(5, 3, 96, 9)
+    ids = np.arange(96, dtype=np.uint32) * 977 + 3
+    acts, wins = ea.predict_mcts(b, d, num_simulations=6, num_env_copies=5, key=0xFEEDFACE12345678, obs_id=ids)
+    oa, ow = po.predict_mcts(b, d, num_simulations=6, num_env_copies=5, key=0xFEEDFACE12345678, obs_id=ids)
+    assert np.array_equal(cpu(wins), ow)
+    assert np.array_equal(cpu(acts), oa)
+    b, d = _random_positions(7, 3, 32, 10)
+    acts, wins = ea.predict_mcts(b, d, num_simulations=8, num_env_copies=1, key=3)
+    oa, ow = po.predict_mcts(b, d, num_simulations=8, num_env_copies=1, key=3)
+    assert np.array_equal(cpu(wins), ow) and np.array_equal(cpu(acts), oa)
+
+
+def test_g9_mcts_statistics_vs_reference(ea, golden):
+    g = golden("g9_mcts.json")
+    for (S, L) in sorted({(r["S"], r["L"]) for r in g}):
+        recs = [r for r in g if (r["S"], r["L"]) == (S, L)]
+        nsim = 2000
+        _, wins = ea.predict_mcts(boards_of(recs, S), [r["dice"] for r in recs], num_simulations=nsim, num_env_copies=1,
+                                  key=99, cube_layer=L)
+        wins = cpu(wins)
+        for i, r in enumerate(recs):
+            for j, w in enumerate(r["wins"]):
+                p = (w + wins[i, j]) / (r["n"] + nsim)
+                sigma = max(1e-9, (p * (1 - p) * (1 / r["n"] + 1 / nsim)) ** 0.5)
+                assert abs(w / r["n"] - wins[i, j] / nsim) <= 5 * sigma + 1e-9, (S, i, j)
+
+
+def test_step_mcts_opponent_vs_oracle(ea):
+    _lockstep(ea, 192, 14, opponent_policy="mcts", num_simulations=3, num_env_copies=2, rng="philox", philox_key=11)
+    _lockstep(ea, 64, 10, opponent_policy="mcts", num_simulations=2, num_env_copies=2, rng="mt19937", philox_key=12)
+
+
+# ---------------------------------------------------------------- full size: properties
+
+def test_full_size_properties_and_sharding(ea):
+    """BASELINE size (65 536 lanes, depth-3 opponent): size-independent checks --
+    determinism, invariance to how lanes are sharded, board invariants, reward/flag
+    consistency, and a sampled slice checked against the oracle."""
+    N, T = 65536, 12
+    kw = dict(opponent_policy="minimax", max_depth=3, rng="philox", philox_key=2024, autoreset=True, seed_stride=N)
+    seeds = (np.arange(N, dtype=np.uint64) + 9487).astype(np.uint32)
+
+    def run(lo, hi):
+        env = ea.VecEWN(hi - lo, lane_offset=lo, **kw)
+        env.reset(seeds=seeds[lo:hi])
+        out = []
+        for t in range(T):
+            a = env.sample_legal_actions(t).clone()
+            res = env.step(a)
+            out.append([x.clone() for x in res] + [a])
+        return out
+
+    full = run(0, N)
+    again = run(0, N)
+    halves = [run(0, N // 2), run(N // 2, N)]
+    for t in range(T):
+        for k in range(7):
+            assert torch.equal(full[t][k], again[t][k])
+            assert torch.equal(full[t][k], torch.cat([halves[0][t][k], halves[1][t][k]]))
+        b, d, r, te, tr, info, a = full[t]
+        bb = b.reshape(N, -1).to(torch.int16)
+        for c in range(1, 7):
+            assert int(((bb == c).sum(1) > 1).sum()) == 0 and int(((bb == -c).sum(1) > 1).sum()) == 0
+        assert int(((d < 1) | (d > 6)).sum()) == 0
+        assert bool(((r != 0) == (te == 1)).all())          # legal agents: reward only on terminal transitions
+        assert bool(((info == 2) == (r > 0)).all()) and bool(((info == 4) == (r < 0)).all())
+        assert int(tr.sum()) == 0
+    # sampled slice against the oracle
+    lo, hi = 30000, 30512
+    orc = po.OracleVecEnv(hi - lo, opponent="minimax", max_depth=3, rng="philox", philox_key=2024, autoreset=True,
+                          seed_stride=N, lane_offset=lo)
+    orc.reset(seeds=seeds[lo:hi])
+    for t in range(T):
+        a = orc.sample_legal_actions(t)
+        assert np.array_equal(cpu(full[t][6][lo:hi]), a)
+        ores = orc.step(a)
+        for k in range(6):
+            x, o = cpu(full[t][k][lo:hi]), ores[k]
+            assert np.array_equal(bits(x) if k == 2 else x, bits(o) if k == 2 else o), (t, k)
