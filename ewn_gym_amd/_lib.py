@@ -20,7 +20,8 @@ INFO_MESSAGES = {
     5: "Invalid move for player! Tolerance left {}.",  # envs/training_ewn.py:56
 }
 
-EXPORTS = ["ewn_abi_version", "ewn_strerror", "ewn_rng_words", "ewn_step_scratch_bytes", "ewn_init_aux", "ewn_reset",
+EXPORTS = ["ewn_abi_version", "ewn_strerror", "ewn_rng_words", "ewn_step_scratch_bytes", "ewn_tables_bytes",
+           "ewn_build_tables", "ewn_init_aux", "ewn_reset",
            "ewn_step", "ewn_legal_actions", "ewn_evaluate", "ewn_predict_minimax", "ewn_predict_random",
            "ewn_predict_mcts"]
 
@@ -40,7 +41,7 @@ class EwnConfig(C.Structure):  # struct ewn_config
 
 class EwnState(C.Structure):  # struct ewn_state
     _fields_ = [("board", C.c_void_p), ("dice", C.c_void_p), ("done", C.c_void_p), ("rng", C.c_void_p),
-                ("prev_score", C.c_void_p), ("tolerance", C.c_void_p)]
+                ("prev_score", C.c_void_p), ("tolerance", C.c_void_p), ("tables", C.c_void_p)]
 
 
 class EwnStepOut(C.Structure):  # struct ewn_step_out
@@ -71,12 +72,14 @@ def load():
         "ewn_strerror": (C.c_char_p, [i32]),
         "ewn_rng_words": (i32, [cfgp]),
         "ewn_step_scratch_bytes": (C.c_int64, [cfgp]),
+        "ewn_tables_bytes": (C.c_int64, [i32, i32]),
+        "ewn_build_tables": (i32, [i32, i32, vp]),
         "ewn_init_aux": (i32, [cfgp, stp, vp]),
         "ewn_reset": (i32, [cfgp, stp, vp, vp, vp]),
         "ewn_step": (i32, [cfgp, stp, vp, outp, vp, vp]),
         "ewn_legal_actions": (i32, [i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
         "ewn_evaluate": (i32, [i32, i32, i32, vp, i32, vp, vp]),
-        "ewn_predict_minimax": (i32, [i32, i32, i32, vp, vp, i32, i32, vp, vp, vp]),
+        "ewn_predict_minimax": (i32, [i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp]),
         "ewn_predict_random": (i32, [i32, i32, i32, vp, vp, u64, u32, i32, vp, vp]),
         "ewn_predict_mcts": (i32, [i32, i32, i32, vp, vp, i32, i32, u64, vp, vp, vp, vp]),
     }

@@ -1,0 +1,251 @@
+// ewn_fast.hpp -- the specialised depth-3 'hybrid' expectiminimax (the headline path).
+//
+// What classical_policies/minimax.py:19-73 computes at max_depth=3:
+//   for each root move a_i (<= 6, reference order):   B1 = apply(B, a_i)
+//     win(B1)            -> v_i = evaluate(B1) = 10
+//     else v_i = sum_{d=1..6} w_d / 6,  w_d = min over BOTTOM_RIGHT's replies to dice d of
+//                        evaluate(B2), the scan stopping early once w_d <= alpha
+//   best = first maximal v_i, alpha = running best.
+//
+// How it is computed here, per lane, with no recursion, no fp64 division, no divergence
+// between the lanes of a wavefront (every loop has a fixed trip count and is predicated):
+//  * cells are renumbered in "ring order" (ascending min(row,col)): the hybrid
+//    heuristic's min-distance of a side (both sides are measured to the bottom-right
+//    corner, envs/minimax_ewn.py:67-76) is then a function of the HIGHEST set bit of its
+//    occupancy mask -- one v_ffbh + one LDS byte instead of a scan;
+//  * a leaf value depends only on (level, count) of either side: <= (8S)^2 cases.  The host
+//    tabulates them in fp64 exactly as Python evaluates them, sorts the distinct values
+//    and hands the kernel an integer RANK per case, so every `val < worst` /
+//    `worst <= alpha` comparison of the reference becomes an integer comparison with the
+//    identical outcome, and w_d/6 is a table read of the host-computed quotient;
+//  * the <= 216 leaves collapse to <= 108 distinct positions (a reply is a (cube, dir)
+//    pair; which two cubes a dice value selects only decides which of those are scanned);
+//  * the reference's early exit "w <= alpha" is replayed in closed form: the reply list is
+//    scanned in order as prefix minima m_1 >= m_2 >= ...; the loop's result is the first
+//    m_j <= alpha, else the last one  ==  max(last, max_j (m_j <= alpha ? m_j : lowest)).
+#pragma once
+#include "ewn_core.hpp"
+
+#define FAST_NV 1024   // distinct leaf values (incl. +-10) must fit 10-bit ranks; rank 1023 = "no such reply"
+#define FAST_NONE 0x3FFFFFFFu
+
+template <int S>
+struct FastTab {
+    static constexpr int IXN = S * 8;            // index of one side's (level t, count n): t*8 + n, n <= 6
+    static constexpr int CELLS = S * S;
+    uint16_t rank[IXN * IXN];                    // [ix(P side)][iy(N side)] -> rank of (0 + x) - y
+    double val[FAST_NV];                         // rank -> leaf value (ascending)
+    double val6[FAST_NV];                        // rank -> value / 6.0 (IEEE quotient, host-computed)
+    uint16_t lutx[72];                           // clz(P mask) -> t*8*IXN   (entry for an empty mask: 0)
+    uint16_t luty[72];                           // clz(N mask) -> t*8
+    uint8_t ri[64];                              // canonical row-major cell -> ring index
+    uint8_t nbp[3][64];                          // mover   (TOP_LEFT):     ring index -> destination ring index, 255 = off board
+    uint8_t nbn[3][64];                          // replier (BOTTOM_RIGHT): ring index -> destination ring index, 255 = off board
+    int32_t nv, ri_origin, pad0, pad1;           // number of ranks; ring index of cell (0,0)
+};
+
+template <int S> struct MaskOf { typedef u32 type; };
+template <> struct MaskOf<6> { typedef u64 type; };
+template <> struct MaskOf<7> { typedef u64 type; };
+template <> struct MaskOf<8> { typedef u64 type; };
+
+EWN_DEV int clz_m(u32 m) { return __clz((int)m); }       // 32 for m == 0
+EWN_DEV int clz_m(u64 m) { return __clzll((long long)m); } // 64 for m == 0
+EWN_DEV int popc_m(u32 m) { return __popc(m); }
+EWN_DEV int popc_m(u64 m) { return __popcll(m); }
+
+// Depth-3 hybrid search on a CANONICAL position (TOP_LEFT = positive side to move).
+// T lives in LDS.  Returns the root value; action in (bflag, bdir).  cube_layer == 3.
+template <int S>
+__device__ __forceinline__ double fast_d3(const FastTab<S> *T, const GState<1> &c, int dice, int &bflag, int &bdir)
+{
+    typedef typename MaskOf<S>::type M;
+    constexpr int IXN = FastTab<S>::IXN;
+    const M one = 1;
+
+    // ---- ring-order masks and positions
+    M P = 0, N = 0;
+    int rn[6];
+    #pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int rp = T->ri[pos_get<1>(c.posP, k)];
+        if ((c.aliveP >> k) & 1u) P |= one << rp;
+        rn[k] = T->ri[pos_get<1>(c.posN, k)];
+        if ((c.aliveN >> k) & 1u) N |= one << rn[k];
+    }
+
+    // ---- the replier's 18 (cube, dir) moves never change during the search
+    M rset[6][3], rclr[6];
+    u32 legal = 0, hits_origin = 0; // bit k*3+dir
+    #pragma unroll
+    for (int k = 0; k < 6; k++) {
+        rclr[k] = ~(one << rn[k]);
+        #pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const int dn = T->nbn[d][rn[k]];
+            const bool ok = dn != 255;
+            rset[k][d] = ok ? (one << dn) : (M)0;
+            legal |= (ok ? 1u : 0u) << (k * 3 + d);
+            hits_origin |= ((ok && dn == T->ri_origin) ? 1u : 0u) << (k * 3 + d);
+        }
+    }
+
+    // ---- root slots: <= 2 cubes x 3 dirs in the reference's list order (envs/ewn.py:338-375)
+    const CubeSel cs = select_cubes(c.aliveP, dice);
+    const bool have0 = cs.exact || cs.has_up, have1 = !cs.exact && cs.has_down;
+    const int k0 = cs.exact ? cs.k_exact : cs.k_up, k1 = cs.k_down;
+    const int flag0 = cs.exact ? 0 : 1;
+    const int rp0 = T->ri[pos_get<1>(c.posP, have0 ? k0 : 0)], rp1 = T->ri[pos_get<1>(c.posP, have1 ? k1 : 0)];
+
+    double best = -__builtin_inf();
+    int A = -1;       // rank threshold: leaf value <= alpha  <=>  rank <= A
+    bflag = 0; bdir = 0;
+
+    #pragma unroll
+    for (int r = 0; r < 6; r++) {
+        const int slot = r / 3, dir = r % 3;
+        const int rp = slot == 0 ? rp0 : rp1;
+        const int dest = T->nbp[dir][rp];
+        const bool valid = (slot == 0 ? have0 : have1) && dest != 255;
+        const M bd = valid ? (one << dest) : (M)0;
+        const M P1 = (P & ~(one << rp)) | bd; // own capture: the bit is already set, the count drops by itself
+        const M N1 = N & ~bd;
+        double v;
+        if (dest == FastTab<S>::CELLS - 1 || N1 == 0) {
+            v = 10.0; // win(B1): evaluate(B1), envs/minimax_ewn.py:42-44
+        } else {
+            // leaves of this root: replier cube k (alive in B1) x dir -> packed prefix minima of ranks
+            u32 tr[6];
+            #pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const bool alive1 = ((c.aliveN >> k) & 1u) && rn[k] != dest;
+                const M Nk = N1 & rclr[k];
+                u32 a[3];
+                #pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    const M N2 = Nk | rset[k][d];
+                    const M P2 = P1 & ~rset[k][d];
+                    const int ix = T->lutx[clz_m(P2)] + popc_m(P2) * IXN;
+                    const int iy = T->luty[clz_m(N2)] + popc_m(N2);
+                    u32 rk = T->rank[ix + iy];
+                    rk = (P2 == 0 || ((hits_origin >> (k * 3 + d)) & 1u)) ? 0u : rk;   // -10: envs/minimax_ewn.py:45-47
+                    a[d] = (alive1 && ((legal >> (k * 3 + d)) & 1u)) ? rk : 1023u;
+                }
+                const u32 p1 = min(a[0], a[1]), p2 = min(p1, a[2]);
+                tr[k] = a[0] | (p1 << 10) | (p2 << 20);
+            }
+            // which cubes a dice value selects (find_near_cube): carry the nearest alive cube's data along
+            u32 upT[6], downT[6];
+            {
+                u32 cur = FAST_NONE;
+                #pragma unroll
+                for (int d = 5; d >= 0; d--) { upT[d] = cur; cur = tr[d] != FAST_NONE ? tr[d] : cur; }
+                cur = FAST_NONE;
+                #pragma unroll
+                for (int d = 0; d < 6; d++) { downT[d] = cur; cur = tr[d] != FAST_NONE ? tr[d] : cur; }
+            }
+            v = 0.0;
+            #pragma unroll
+            for (int d = 0; d < 6; d++) {
+                const bool exact = tr[d] != FAST_NONE;
+                const bool up = upT[d] != FAST_NONE;
+                const u32 F = exact ? tr[d] : (up ? upT[d] : downT[d]);
+                const u32 G = (!exact && up) ? downT[d] : FAST_NONE;
+                const int x0 = (int)(F & 1023u), x1 = (int)((F >> 10) & 1023u), x2 = (int)(F >> 20);
+                const int y0 = min(x2, (int)(G & 1023u)), y1 = min(x2, (int)((G >> 10) & 1023u)), y2 = min(x2, (int)(G >> 20));
+                int w = y2; // the full minimum: what the loop returns when it never breaks
+                w = max(w, x0 <= A ? x0 : 0);
+                w = max(w, x1 <= A ? x1 : 0);
+                w = max(w, x2 <= A ? x2 : 0);
+                w = max(w, y0 <= A ? y0 : 0);
+                w = max(w, y1 <= A ? y1 : 0);
+                v = v + T->val6[w]; // expected_val += val / 6, minimax.py:72
+            }
+        }
+        if (valid && v > best) {
+            best = v; bflag = slot == 0 ? flag0 : 0; bdir = dir;
+        }
+        if (r < 5) {
+            // alpha = max(alpha, best): largest rank whose value is <= best (val[] ascending); -1 if none
+            int lo = -1, hi = T->nv - 1;
+            #pragma unroll 1
+            for (int it = 0; it < 10; it++) {
+                const int mid = (lo + hi + 1) >> 1;
+                const bool le = T->val[max(mid, 0)] <= best;
+                lo = le ? mid : lo;
+                hi = le ? hi : mid - 1;
+            }
+            A = lo;
+        }
+    }
+    return best;
+}
+
+// ---------------------------------------------------------------- host: table construction
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+template <int S>
+static int build_fast_tables(FastTab<S> *T)
+{
+    constexpr int IXN = FastTab<S>::IXN;
+    memset(T, 0, sizeof(*T));
+    // ring order: ascending level t = min(row, col); (0,0) first, (S-1,S-1) last
+    int ring_of_rm[64], rm_of_ring[64], n = 0;
+    for (int t = 0; t < S; t++)
+        for (int i = 0; i < S; i++)
+            for (int j = 0; j < S; j++)
+                if ((i < j ? i : j) == t) { ring_of_rm[i * S + j] = n; rm_of_ring[n] = i * S + j; n++; }
+    int level_of_ring[64];
+    for (int q = 0; q < S * S; q++) { const int c = rm_of_ring[q]; level_of_ring[q] = (c / S < c % S) ? c / S : c % S; }
+    for (int c = 0; c < 64; c++) T->ri[c] = c < S * S ? (uint8_t)ring_of_rm[c] : 0;
+    T->ri_origin = ring_of_rm[0];
+    for (int d = 0; d < 3; d++)
+        for (int q = 0; q < 64; q++) {
+            T->nbp[d][q] = 255; T->nbn[d][q] = 255;
+            if (q >= S * S) continue;
+            const int c = rm_of_ring[q], i = c / S, j = c % S;
+            const int di = d == 0 ? 0 : 1, dj = d == 1 ? 0 : 1;
+            if (i + di < S && j + dj < S) T->nbp[d][q] = (uint8_t)ring_of_rm[(i + di) * S + (j + dj)];
+            if (i - di >= 0 && j - dj >= 0) T->nbn[d][q] = (uint8_t)ring_of_rm[(i - di) * S + (j - dj)];
+        }
+    const int W = S <= 5 ? 32 : 64;
+    for (int z = 0; z <= W; z++) {
+        const int h = W - 1 - z; // highest set bit
+        const int t = (z == W || h >= S * S) ? 0 : level_of_ring[h];
+        T->lutx[z] = (uint16_t)(t * 8 * IXN);
+        T->luty[z] = (uint16_t)(t * 8);
+    }
+    // leaf values: score = 0; score += (L - mdP) * (1 / nP); score -= (L - mdN) * (1 / nN)   (envs/minimax_ewn.py:79-82)
+    // with L = S, md = S - 1 - t.  volatile keeps every rounding step a separate fp64 operation.
+    std::vector<double> all;
+    std::vector<double> e((size_t)IXN * IXN, 0.0);
+    for (int tp = 0; tp < S; tp++) for (int np_ = 1; np_ <= 6; np_++)
+        for (int tn = 0; tn < S; tn++) for (int nn = 1; nn <= 6; nn++) {
+            volatile double rp = 1.0 / (double)np_, rn_ = 1.0 / (double)nn;
+            volatile double x = (double)(tp + 1) * rp, y = (double)(tn + 1) * rn_;
+            volatile double s0 = 0.0 + x;
+            volatile double s1 = s0 - y;
+            const double ev = s1;
+            e[(size_t)(tp * 8 + np_) * IXN + (tn * 8 + nn)] = ev;
+            all.push_back(ev);
+        }
+    all.push_back(-10.0);
+    all.push_back(10.0);
+    std::sort(all.begin(), all.end());
+    all.erase(std::unique(all.begin(), all.end()), all.end());
+    if ((int)all.size() > FAST_NV - 1) return -1;
+    T->nv = (int)all.size();
+    for (int i = 0; i < FAST_NV; i++) {
+        const double v = i < T->nv ? all[i] : all.back();
+        volatile double q = v / 6.0;
+        T->val[i] = v; T->val6[i] = q;
+    }
+    for (int ix = 0; ix < IXN; ix++)
+        for (int iy = 0; iy < IXN; iy++) {
+            const bool used = (ix % 8) >= 1 && (ix % 8) <= 6 && (iy % 8) >= 1 && (iy % 8) <= 6;
+            T->rank[ix * IXN + iy] = used ? (uint16_t)(std::lower_bound(all.begin(), all.end(), e[(size_t)ix * IXN + iy]) - all.begin()) : 0;
+        }
+    return 0;
+}

@@ -7,6 +7,7 @@
 // scheduling, not the unit of work -- a 25-cell board would leave 39 of 64 lanes
 // idle if a whole wavefront served one game.
 #include "ewn_core.hpp"
+#include "ewn_fast.hpp"
 #include "../../include/ewn_hip.h"
 
 #define BS 256
@@ -19,7 +20,7 @@ struct KCfg {
 };
 
 struct KState {
-    int8_t *board; int8_t *dice; uint8_t *done; u32 *rng; double *prev_score; int32_t *tolerance;
+    int8_t *board; int8_t *dice; uint8_t *done; u32 *rng; double *prev_score; int32_t *tolerance; const void *tables;
 };
 
 struct KOut {
@@ -187,11 +188,18 @@ __global__ __launch_bounds__(BS) void k_init_aux(Geom g, KCfg c, KState st, int 
 // PHASE 1: agent half only; a lane that still needs the opponent's reply leaves its
 //          canonical observation in scratch for a policy kernel (sc.phase[lane] = 1)
 // PHASE 2: opponent half for the lanes with sc.phase[lane] == 1, action taken from scratch
-template <int NW, int PHASE>
+// FAST = board size S of the specialised depth-3 policy (ewn_fast.hpp), 0 = generic policies
+template <int NW, int PHASE, int FAST>
 __global__ __launch_bounds__(BS) void k_step(Geom g, KCfg c, KState st, const int8_t *actions, KOut out, KScratch sc)
 {
-    extern __shared__ int8_t lds[];
+    extern __shared__ __attribute__((aligned(16))) int8_t lds[];
     int8_t *lds_t = lds + BS * g.cells; // terminal-observation staging
+    [[maybe_unused]] const FastTab<(FAST ? FAST : 5)> *ftab = nullptr;
+    if constexpr (FAST != 0) {
+        int8_t *tb = lds + ((2 * BS * g.cells + 15) & ~15);
+        block_copy_in(tb, (const int8_t *)st.tables, (int)sizeof(FastTab<(FAST ? FAST : 5)>));
+        ftab = (const FastTab<(FAST ? FAST : 5)> *)tb;
+    }
     const int lane0 = blockIdx.x * BS, nl = min(BS, c.N - lane0), lane = lane0 + threadIdx.x;
     block_copy_in(lds, st.board + (size_t)lane0 * g.cells, nl * g.cells);
     if (PHASE == 2 && out.tboard) block_copy_in(lds_t, out.tboard + (size_t)lane0 * g.cells, nl * g.cells);
@@ -234,7 +242,10 @@ __global__ __launch_bounds__(BS) void k_step(Geom g, KCfg c, KState st, const in
                         settled = false;
                     }
                 } else if (reply) {
-                    if (PHASE == 0) {
+                    if constexpr (FAST != 0) {
+                        const GState<1> cst = canonicalize<1>(g, s);
+                        fast_d3<(FAST ? FAST : 5)>(ftab, cst, dice, oflag, odir);
+                    } else if (PHASE == 0) {
                         if (c.opp == EWN_OPP_RANDOM) policy_random<NW>(g, s, dice, r, oflag, odir);
                         else policy_minimax_rt<NW>(g, s, dice, c.depth, c.heur, oflag, odir);
                     }
@@ -318,6 +329,29 @@ __global__ __launch_bounds__(BS) void k_predict_minimax(Geom g, int M, const int
     const int dc = dice[m];
     if (s.aliveP != 0 && dc >= 1 && dc <= g.CN)
         v = search<NW, DEPTH, 0, true>(g, s, dc, -__builtin_inf(), __builtin_inf(), heur, f, d);
+    actions[2 * m] = (int8_t)f; actions[2 * m + 1] = (int8_t)d;
+    if (values) values[m] = v;
+}
+
+template <int S>
+__global__ __launch_bounds__(BS) void k_predict_minimax_fast(Geom g, int M, const int8_t *boards, const int8_t *dice,
+                                                             int8_t *actions, double *values, const void *tables)
+{
+    extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+    block_copy_in(lds, (const int8_t *)tables, (int)sizeof(FastTab<S>));
+    __syncthreads();
+    const FastTab<S> *T = (const FastTab<S> *)lds;
+    const int m = blockIdx.x * BS + threadIdx.x;
+    if (m >= M) return;
+    GState<1> s;
+    decode_board<1>(g, boards + (size_t)m * g.cells, s);
+    int f = -1, d = -1;
+    double v = 0.0;
+    const int dc = dice[m];
+    if (s.aliveP != 0 && dc >= 1 && dc <= g.CN) {
+        if (is_win<1>(g, s)) v = evaluate<1>(g, s, EWN_H_HYBRID);
+        else v = fast_d3<S>(T, s, dc, f, d);
+    }
     actions[2 * m] = (int8_t)f; actions[2 * m + 1] = (int8_t)d;
     if (values) values[m] = v;
 }
@@ -492,6 +526,19 @@ static int launch_status()
     return hipGetLastError() == hipSuccess ? EWN_OK : EWN_ELAUNCH;
 }
 
+// specialised depth-3 tables exist for cube_layer 3 and board sizes whose distinct leaf values fit 10-bit ranks
+static int64_t fast_tables_bytes(int S, int L)
+{
+    if (L != 3) return 0;
+    switch (S) {
+    case 5: return (int64_t)sizeof(FastTab<5>);
+    case 6: return (int64_t)sizeof(FastTab<6>);
+    case 7: return (int64_t)sizeof(FastTab<7>);
+    case 8: return (int64_t)sizeof(FastTab<8>);
+    default: return 0;
+    }
+}
+
 #define GRID(n) dim3((unsigned)(((long long)(n) + BS - 1) / BS))
 #define BY_NW(g, expr1, expr2) do { if ((g).CN <= 10) { expr1; } else { expr2; } } while (0)
 
@@ -523,6 +570,27 @@ const char *ewn_strerror(int code)
     case EWN_EUNSUPPORTED: return "configuration valid upstream but not supported by this build";
     default: return "unknown error";
     }
+}
+
+int64_t ewn_tables_bytes(int board_size, int cube_layer)
+{
+    Geom g;
+    if (!make_geom(board_size, cube_layer, g)) return 0;
+    return fast_tables_bytes(board_size, cube_layer);
+}
+
+int ewn_build_tables(int board_size, int cube_layer, void *host_out)
+{
+    if (!host_out) return EWN_ENULL;
+    if (ewn_tables_bytes(board_size, cube_layer) <= 0) return EWN_EUNSUPPORTED;
+    int rc = -1;
+    switch (board_size) {
+    case 5: rc = build_fast_tables<5>((FastTab<5> *)host_out); break;
+    case 6: rc = build_fast_tables<6>((FastTab<6> *)host_out); break;
+    case 7: rc = build_fast_tables<7>((FastTab<7> *)host_out); break;
+    case 8: rc = build_fast_tables<8>((FastTab<8> *)host_out); break;
+    }
+    return rc == 0 ? EWN_OK : EWN_EUNSUPPORTED;
 }
 
 int ewn_rng_words(const ewn_config *cfg)
@@ -558,7 +626,7 @@ static void carve_scratch(const Geom &g, const KCfg &k, void *scratch, KScratch 
 
 static KState kstate(const ewn_state *st)
 {
-    KState s = { st->board, st->dice, st->done, st->rng, st->prev_score, st->tolerance };
+    KState s = { st->board, st->dice, st->done, st->rng, st->prev_score, st->tolerance, st->tables };
     return s;
 }
 
@@ -620,20 +688,32 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
     KScratch sc = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     const size_t lds = (size_t)2 * BS * g.cells;
     if (cfg->opponent_kind != EWN_OPP_MCTS) {
-        BY_NW(g, (k_step<1, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)),
-              (k_step<2, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)));
+        const bool fast = st->tables && fast_tables_bytes(g.S, g.L) > 0 && cfg->opponent_kind == EWN_OPP_MINIMAX &&
+                          cfg->max_depth == 3 && cfg->heuristic == EWN_H_HYBRID;
+        if (fast) {
+            const size_t base = (lds + 15) & ~(size_t)15;
+            switch (g.S) {
+            case 5: k_step<1, 0, 5><<<GRID(k.N), BS, base + sizeof(FastTab<5>), s>>>(g, k, ks, actions, ko, sc); break;
+            case 6: k_step<1, 0, 6><<<GRID(k.N), BS, base + sizeof(FastTab<6>), s>>>(g, k, ks, actions, ko, sc); break;
+            case 7: k_step<1, 0, 7><<<GRID(k.N), BS, base + sizeof(FastTab<7>), s>>>(g, k, ks, actions, ko, sc); break;
+            default: k_step<1, 0, 8><<<GRID(k.N), BS, base + sizeof(FastTab<8>), s>>>(g, k, ks, actions, ko, sc); break;
+            }
+            return launch_status();
+        }
+        BY_NW(g, (k_step<1, 0, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)),
+              (k_step<2, 0, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)));
         return launch_status();
     }
     if (!scratch) return EWN_ENULL;
     carve_scratch(g, k, scratch, sc);
-    BY_NW(g, (k_step<1, 1><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)),
-          (k_step<2, 1><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)));
+    BY_NW(g, (k_step<1, 1, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)),
+          (k_step<2, 1, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)));
     rc = launch_status();
     if (rc) return rc;
     rc = mcts_launch(g, k.N, sc.cboard, sc.cdice, sc.phase, k.nsim_total, k.key, sc.obs_id, sc.act, sc.wins, s);
     if (rc) return rc;
-    BY_NW(g, (k_step<1, 2><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)),
-          (k_step<2, 2><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)));
+    BY_NW(g, (k_step<1, 2, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)),
+          (k_step<2, 2, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)));
     return launch_status();
 }
 
@@ -675,7 +755,7 @@ int ewn_evaluate(int board_size, int cube_layer, int M, const int8_t *boards, in
 }
 
 int ewn_predict_minimax(int board_size, int cube_layer, int M, const int8_t *boards, const int8_t *dice, int max_depth,
-                        int heuristic, int8_t *actions, double *values, void *stream)
+                        int heuristic, int8_t *actions, double *values, const void *tables, void *stream)
 {
     Geom g;
     int rc = query_geom(board_size, cube_layer, M, boards, g);
@@ -685,6 +765,15 @@ int ewn_predict_minimax(int board_size, int cube_layer, int M, const int8_t *boa
     if (M == 0) return EWN_OK;
     if (!dice || !actions) return EWN_ENULL;
     hipStream_t s = (hipStream_t)stream;
+    if (tables && fast_tables_bytes(g.S, g.L) > 0 && max_depth == 3 && heuristic == EWN_H_HYBRID) {
+        switch (g.S) {
+        case 5: k_predict_minimax_fast<5><<<GRID(M), BS, sizeof(FastTab<5>), s>>>(g, M, boards, dice, actions, values, tables); break;
+        case 6: k_predict_minimax_fast<6><<<GRID(M), BS, sizeof(FastTab<6>), s>>>(g, M, boards, dice, actions, values, tables); break;
+        case 7: k_predict_minimax_fast<7><<<GRID(M), BS, sizeof(FastTab<7>), s>>>(g, M, boards, dice, actions, values, tables); break;
+        default: k_predict_minimax_fast<8><<<GRID(M), BS, sizeof(FastTab<8>), s>>>(g, M, boards, dice, actions, values, tables); break;
+        }
+        return launch_status();
+    }
     BY_NW(g, launch_minimax<1>(g, M, boards, dice, max_depth, heuristic, actions, values, s),
           launch_minimax<2>(g, M, boards, dice, max_depth, heuristic, actions, values, s));
     return launch_status();

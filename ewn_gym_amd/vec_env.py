@@ -29,11 +29,30 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_TABLES = {}
+
+
+def search_tables(board_size, cube_layer, device):
+    """Device copy of the depth-3 search tables (built on the host by ewn_build_tables), or None."""
+    key = (int(board_size), int(cube_layer), str(device))
+    if key not in _TABLES:
+        lib = _lib.load()
+        n = int(lib.ewn_tables_bytes(key[0], key[1]))
+        t = None
+        if n > 0:
+            host = np.zeros(n, dtype=np.uint8)
+            check(lib.ewn_build_tables(key[0], key[1], host.ctypes.data_as(C.c_void_p)), "ewn_build_tables")
+            t = torch.from_numpy(host).to(device)
+        _TABLES[key] = t
+    return _TABLES[key]
+
+
 class VecEWN:
     def __init__(self, n_lanes, board_size=5, cube_layer=3, opponent_policy="random", max_depth=3, heuristic="hybrid",
                  num_simulations=10, num_env_copies=5, rng="mt19937", shaped=False, reward=1.0,
                  illegal_move_reward=-1.0, illegal_move_tolerance=10, autoreset=False, shaped_refresh_on_reset=False,
-                 lane_offset=0, seed_stride=None, philox_key=0, mt_window=0, want_terminal_obs=False, device="cuda"):
+                 lane_offset=0, seed_stride=None, philox_key=0, mt_window=0, want_terminal_obs=False, device="cuda",
+                 use_tables=True):
         self.lib = _lib.load()
         opp = str(opponent_policy)
         if opp not in OPP:
@@ -65,8 +84,9 @@ class VecEWN:
         nscr = check(self.lib.ewn_step_scratch_bytes(C.byref(self.cfg)), "ewn_step_scratch_bytes")
         self.scratch = torch.zeros(max(int(nscr), 8), dtype=torch.uint8, device=dev)
         self._actions = torch.zeros((N, 2), dtype=torch.int8, device=dev)
+        self.tables = search_tables(self.S, self.L, dev) if use_tables else None
         self._st = EwnState(_ptr(self.board), _ptr(self.dice), _ptr(self.done), _ptr(self.rng_state),
-                            _ptr(self.prev_score), _ptr(self.tolerance))
+                            _ptr(self.prev_score), _ptr(self.tolerance), _ptr(self.tables))
         self._out = EwnStepOut(_ptr(self.reward), _ptr(self.terminated), _ptr(self.truncated), _ptr(self.info),
                                _ptr(self.terminal_board), _ptr(self.terminal_dice))
         check(self.lib.ewn_init_aux(C.byref(self.cfg), C.byref(self._st), _stream()), "ewn_init_aux")
@@ -157,15 +177,16 @@ def evaluate(boards, heuristic="hybrid", cube_layer=3):
     return out
 
 
-def predict_minimax(boards, dice, max_depth, heuristic="hybrid", cube_layer=3):
+def predict_minimax(boards, dice, max_depth, heuristic="hybrid", cube_layer=3, use_tables=True):
     lib = _lib.load()
     if heuristic not in HEUR:
         raise _lib.EwnError("heuristic %r is not supported" % heuristic)
     b, d, M, S, dev = _prep(boards, dice)
     acts = torch.zeros((M, 2), dtype=torch.int8, device=dev)
     vals = torch.zeros(M, dtype=torch.float64, device=dev)
+    tables = search_tables(S, cube_layer, dev) if use_tables else None
     check(lib.ewn_predict_minimax(S, cube_layer, M, _ptr(b), _ptr(d), int(max_depth), HEUR[heuristic], _ptr(acts),
-                                  _ptr(vals), _stream()), "ewn_predict_minimax")
+                                  _ptr(vals), _ptr(tables), _stream()), "ewn_predict_minimax")
     return acts, vals
 
 

@@ -104,6 +104,9 @@ typedef struct ewn_state {
     uint32_t *rng;       /* [N][ewn_rng_words()]  {seed, draw index, next_seed, 0, MT window...} */
     double *prev_score;  /* [N]  shaped env only (training_ewn.py:35), may be NULL otherwise */
     int32_t *tolerance;  /* [N]  shaped env only (training_ewn.py:38), may be NULL otherwise */
+    const void *tables;  /* device copy of ewn_build_tables() output, or NULL.  When present and the config is
+                            (cube_layer 3, minimax, max_depth 3, 'hybrid') ewn_step runs the specialised
+                            depth-3 kernel; results are identical either way. */
 } ewn_state;
 
 /* Outputs of one step, device pointers, caller-owned.  The post-step observation is
@@ -124,6 +127,13 @@ const char *ewn_strerror(int code);
 int ewn_rng_words(const ewn_config *cfg);
 /* bytes of device scratch ewn_step needs for this config (0 if none; <0 on error) */
 int64_t ewn_step_scratch_bytes(const ewn_config *cfg);
+
+/* Search tables of the specialised depth-3 kernel (leaf-value ranks, ring-order geometry;
+ * ewn_gym_amd/csrc/ewn_fast.hpp).  Pure host computation: ewn_tables_bytes() gives the size
+ * (0 = no specialised kernel for this geometry), ewn_build_tables() fills a HOST buffer the
+ * caller then copies to the device and passes as ewn_state.tables / the `tables` argument. */
+int64_t ewn_tables_bytes(int board_size, int cube_layer);
+int ewn_build_tables(int board_size, int cube_layer, void *host_out);
 
 /* Constructor-time state that reset() does not touch in the reference:
  * prev_score = evaluate(initial board) (training_ewn.py:35) and the tolerance
@@ -155,9 +165,10 @@ int ewn_legal_actions(int board_size, int cube_layer, int M, const int8_t *board
 int ewn_evaluate(int board_size, int cube_layer, int M, const int8_t *boards, int heuristic, double *out, void *stream);
 
 /* ExpectiMinimaxAgent.predict (classical_policies/minimax.py:89-93): actions [M][2];
- * values [M] = root value (may be NULL). */
+ * values [M] = root value (may be NULL); tables: see ewn_build_tables (may be NULL).
+ * A position that is already won/lost returns action {-1,-1} and value = evaluate(). */
 int ewn_predict_minimax(int board_size, int cube_layer, int M, const int8_t *boards, const int8_t *dice, int max_depth,
-                        int heuristic, int8_t *actions, double *values, void *stream);
+                        int heuristic, int8_t *actions, double *values, const void *tables, void *stream);
 
 /* RandomAgent.predict (classical_policies/random_policy.py:11-15) as a stateless policy:
  * uniform legal action from Philox ctr={step, lane_offset+i, 'AGNT', 0}, key. */

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     assert C.sizeof(EwnConfig) == 14 * 4 + 2 * 4 + 2 * 8 + 8
-    assert C.sizeof(_lib.EwnState) == 6 * 8 and C.sizeof(_lib.EwnStepOut) == 6 * 8
+    assert C.sizeof(_lib.EwnState) == 7 * 8 and C.sizeof(_lib.EwnStepOut) == 6 * 8
 
 
 def test_config_validation_on_host():
@@ -62,8 +62,8 @@ def test_null_pointers_are_rejected_before_any_launch():
     assert lib.ewn_init_aux(C.byref(cfg()), None, None) == -2
     assert lib.ewn_evaluate(5, 3, 4, None, 0, None, None) == -2
     assert lib.ewn_evaluate(5, 3, 0, None, 0, None, None) == 0            # empty batch is a no-op
-    assert lib.ewn_predict_minimax(5, 3, 0, None, None, 3, 0, None, None, None) == 0
-    assert lib.ewn_predict_minimax(5, 3, 0, None, None, 0, 0, None, None, None) == -1
+    assert lib.ewn_predict_minimax(5, 3, 0, None, None, 3, 0, None, None, None, None) == 0
+    assert lib.ewn_predict_minimax(5, 3, 0, None, None, 0, 0, None, None, None, None) == -1
     assert lib.ewn_evaluate(5, 3, 0, None, 4, None, None) == -4            # 'sim_winrate' not built
     assert lib.ewn_legal_actions(5, 3, 0, None, None, 3, None, None, None, None, None, None) == -1  # Player.CHANCE
 

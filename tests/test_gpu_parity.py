@@ -169,6 +169,7 @@ def _lockstep(ea, N, steps, seed0=1000, check_terminal=True, **kw):
     opp = okw.pop("opponent_policy", "random")
     env = ea.VecEWN(N, opponent_policy=opp, autoreset=True, want_terminal_obs=check_terminal, **okw)
     okw.pop("mt_window", None)
+    okw.pop("use_tables", None)
     orc = po.OracleVecEnv(N, opponent=opp, autoreset=True, **okw)
     seeds = np.arange(N, dtype=np.uint32) * 7919 + seed0
     b, d = env.reset(seeds=seeds)
@@ -262,14 +263,18 @@ def test_frozen_lanes_without_autoreset(ea):
 
 # ---------------------------------------------------------------- stateless policies
 
-def _random_positions(S, L, n, seed):
+def _random_positions(S, L, n, seed, max_steps=14):
+    """Reachable non-terminal positions from every phase of the game (opening to few-cube endgames)."""
     orc = po.OracleVecEnv(n, board_size=S, cube_layer=L, rng="philox", philox_key=seed, autoreset=True)
     orc.reset(seeds=np.arange(n) + seed)
     gen = np.random.Generator(np.random.PCG64(seed))
-    for t in range(int(gen.integers(1, 6))):
-        orc.step(orc.sample_legal_actions(t))
-    b, _ = orc.obs()
-    return b, gen.integers(1, 7, n).astype(np.int8)
+    when = gen.integers(0, max_steps, n)
+    out, _ = orc.obs()
+    out = out.copy()
+    for t in range(max_steps):
+        b = orc.step(orc.sample_legal_actions(t))[0]
+        out[when == t] = b[when == t]
+    return out, gen.integers(1, 7, n).astype(np.int8)
 
 
 @pytest.mark.parametrize("S,L,depth,heur,n", [(5, 3, 3, "hybrid", 6000), (5, 3, 2, "min_dist", 1500), (5, 3, 4, "hybrid", 300),
@@ -281,6 +286,22 @@ def test_predict_minimax_vs_oracle(ea, S, L, depth, heur, n):
     oa, ov, _ = po.predict_minimax(b, d, depth, heur, cube_layer=L)
     assert np.array_equal(cpu(acts), oa)
     assert np.array_equal(bits(cpu(vals)), bits(ov))
+
+
+@pytest.mark.parametrize("S", [5, 6, 7, 8])
+def test_depth3_specialised_kernel_equals_generic_and_oracle(ea, S):
+    """The table-driven depth-3 kernel (ewn_fast.hpp) vs the template-recursive one vs the oracle."""
+    n = 20000 if S == 5 else 4000
+    b, d = _random_positions(S, 3, n, 1234 + S, max_steps=14 if S == 5 else 24)
+    fa, fv = ea.predict_minimax(b, d, 3, "hybrid", use_tables=True)
+    ga, gv = ea.predict_minimax(b, d, 3, "hybrid", use_tables=False)
+    oa, ov, _ = po.predict_minimax(b, d, 3, "hybrid")
+    assert np.array_equal(cpu(fa), oa) and np.array_equal(cpu(ga), oa)
+    assert np.array_equal(bits(cpu(fv)), bits(ov)) and np.array_equal(bits(cpu(gv)), bits(ov))
+
+
+def test_step_generic_depth3_kernel_still_covered(ea):
+    _lockstep(ea, 1000, 20, opponent_policy="minimax", max_depth=3, rng="philox", use_tables=False)
 
 
 def test_pruned_search_differs_from_full_width_somewhere(ea, golden):
