@@ -1,0 +1,172 @@
+"""EinsteinWuerfeltNichtEnv: the reference's gymnasium environment (envs/ewn.py:18-576)
+as a single-lane view of the MI355X engine.  All rules, dice and the opponent's reply
+run in libewn_hip.so; this class only mirrors the API surface and keeps host copies of
+the observation for callers that read `env.board` / `env.dice_roll`."""
+import os
+from typing import List, Optional
+
+import numpy as np
+
+from constants import ClassicalPolicy, Player
+
+try:  # gymnasium is optional: the reference needs it, the engine does not
+    import gymnasium as gym
+    from gymnasium import spaces
+    from gymnasium.error import DependencyNotInstalled
+    _Base = gym.Env
+except ImportError:  # pragma: no cover - depends on the image
+    from ewn_gym_amd import spaces_compat as spaces
+    from ewn_gym_amd.spaces_compat import DependencyNotInstalled
+    _Base = object
+
+VIEWPORT_SIZE = 700
+FPS = 30
+
+
+class EinsteinWuerfeltNichtEnv(_Base):
+    metadata = {"render_modes": ["human", "rgb_array", "ansi"], "render_fps": FPS}
+    _shaped = False
+
+    def __init__(self, board_size: int = 5, cube_layer: int = 3, seed: int = 9487, reward: float = 1.,
+                 agent_player: Player = Player.TOP_LEFT, render_mode: Optional[str] = None,
+                 opponent_policy=ClassicalPolicy.random, **policy_kwargs):
+        super().__init__()
+        assert cube_layer < board_size - 1                      # envs/ewn.py:47
+        if agent_player != Player.TOP_LEFT:
+            # the reference's BOTTOM_RIGHT-agent branch (:110-129) is dead/broken upstream
+            raise NotImplementedError("only agent_player=Player.TOP_LEFT is supported")
+        self.board = np.zeros((board_size, board_size), dtype=np.int16)
+        self.cube_num = cube_layer * (cube_layer + 1) // 2
+        self.cube_layer = cube_layer
+        self.dice_roll = 1
+        self.action_space = spaces.MultiDiscrete([2, 3])
+        self.observation_space = spaces.Dict({
+            "board": spaces.Box(low=-self.cube_num, high=self.cube_num, shape=(board_size, board_size), dtype=np.int16),
+            "dice_roll": spaces.Discrete(self.cube_num + 1, start=1),  # width cube_num+1: the SB3 one-hot workaround, :66-68
+        })
+        self.current_player = Player.TOP_LEFT
+        self.agent_player = agent_player
+        self.reward = reward
+        assert opponent_policy is not None
+        self._policy_kwargs = dict(policy_kwargs)
+        self.load_opponent_policy(opponent_policy, **policy_kwargs)
+        self._engine = self._make_engine()
+        self.reset(seed=seed)
+        self.render_mode = render_mode
+        self.screen = None
+        self.clock = None
+        self.surf = None
+        self.history = []
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _engine_kwargs(self):
+        kw = self._policy_kwargs
+        return dict(board_size=self.board.shape[0], cube_layer=self.cube_layer, opponent_policy=str(self._opponent_kind),
+                    max_depth=kw.get("max_depth", 3), heuristic=kw.get("heuristic", "hybrid"),
+                    num_simulations=kw.get("num_simulations", 10), num_env_copies=kw.get("num_env_copies", 5),
+                    rng="mt19937", reward=self.reward, philox_key=int.from_bytes(os.urandom(8), "little"))
+
+    def _make_engine(self):
+        import ewn_gym_amd
+        return ewn_gym_amd.VecEWN(1, **self._engine_kwargs())
+
+    def _pull(self):
+        self.board[:] = self._engine.board[0].cpu().numpy()     # in place: obs["board"] aliases env state upstream too
+        self.dice_roll = int(self._engine.dice[0].item())
+
+    def _obs(self):
+        return {"board": self.board, "dice_roll": self.dice_roll}
+
+    # ------------------------------------------------------------------ reference API
+    def load_opponent_policy(self, opponent_policy, **policy_kwargs):
+        """envs/ewn.py:265-287.  The reply itself is computed inside the fused step kernel;
+        the agent object is kept for introspection (`env.opponent_policy`)."""
+        from classical_policies import ExpectiMinimaxAgent, MctsAgent, RandomAgent
+        if opponent_policy == ClassicalPolicy.random:
+            self.opponent_policy = RandomAgent(self)
+        elif opponent_policy == ClassicalPolicy.minimax:
+            self.opponent_policy = ExpectiMinimaxAgent(cube_layer=self.cube_layer, board_size=self.board.shape[0],
+                                                       **policy_kwargs)  # max_depth is required, as upstream
+        elif opponent_policy == ClassicalPolicy.mcts:
+            self.opponent_policy = MctsAgent(cube_layer=self.cube_layer, board_size=self.board.shape[0], **policy_kwargs)
+        elif isinstance(opponent_policy, ClassicalPolicy):
+            raise NotImplementedError("opponent policy %s is out of scope of the HIP engine" % opponent_policy)
+        else:
+            assert isinstance(opponent_policy, str)
+            raise NotImplementedError("SB3 checkpoint opponents (A2C.load, envs/ewn.py:287) need stable_baselines3")
+        self._opponent_kind = opponent_policy
+
+    def reset(self, seed: Optional[int] = None):
+        """envs/ewn.py:488-494.  seed=None draws OS entropy, like np.random.seed(None)."""
+        self.current_player = Player.TOP_LEFT
+        if seed is None:
+            seed = int.from_bytes(os.urandom(4), "little")
+        np.random.seed(seed)          # the reference seeds the GLOBAL numpy stream here; host-side agents rely on it
+        self.action_space.seed(seed)
+        self._engine.reset(seeds=[int(seed) & 0xFFFFFFFF])
+        self._pull()
+        return self._obs(), {}
+
+    def step(self, action):
+        """envs/ewn.py:436-486 -> (obs, reward, terminated, truncated, info)"""
+        import ewn_gym_amd
+        a = np.asarray(action).reshape(-1)
+        _, _, r, te, tr, info = self._engine.step(np.array([[int(a[0]), int(a[1])]], dtype=np.int8))
+        self._pull()
+        code = int(info[0].item())
+        msg = ewn_gym_amd.INFO_MESSAGES[code]
+        if code == 5:
+            msg = msg.format(int(self._engine.tolerance[0].item()))
+        self.current_player = Player.BOTTOM_RIGHT if code in (3, 4) else Player.TOP_LEFT
+        return self._obs(), float(r[0].item()), bool(te[0].item()), bool(tr[0].item()), ({"message": msg} if msg else {})
+
+    def roll_dice(self):
+        raise NotImplementedError("dice are rolled on the device inside reset()/step()")
+
+    def switch_player(self):
+        self.current_player = Player.get_opponent(self.current_player)
+
+    def _query(self, player):
+        import ewn_gym_amd
+        return [t.cpu().numpy() for t in ewn_gym_amd.legal_actions(self.board.astype(np.int8)[None], [self.dice_roll],
+                                                                   player=player.value, cube_layer=self.cube_layer)]
+
+    def check_win(self) -> bool:
+        return bool(self._query(Player.TOP_LEFT)[4][0])
+
+    def get_legal_actions(self, player: Player) -> List[List[int]]:
+        if player == Player.CHANCE:
+            raise ValueError("Invalid player")
+        acts, n = self._query(player)[:2]
+        return [[int(a[0]), int(a[1])] for a in acts[0, :int(n[0])]]
+
+    def find_cube_to_move(self, chose_larger: bool, player: Optional[Player] = None) -> int:
+        player = self.current_player if player is None else player
+        q = self._query(player)
+        num = int(q[3][0] if chose_larger else q[2][0])
+        assert num != 0
+        return num - 1 if player == Player.TOP_LEFT else -num    # python-style index into cube_pos, :185-186
+
+    @property
+    def cube_pos(self):
+        """The reference's masked structured array of cube coordinates (envs/ewn.py:57), rebuilt from the board."""
+        cp = np.ma.zeros((self.cube_num * 2,), dtype=[("x", int), ("y", int)])
+        cp[:] = np.ma.masked
+        for (i, j), c in np.ndenumerate(self.board):
+            if c > 0:
+                cp[c - 1] = (i, j)
+            elif c < 0:
+                cp[c] = (i, j)
+        return cp
+
+    def render(self):
+        if self.render_mode == "ansi":                           # envs/ewn.py:498-502
+            print("dice:")
+            print(self.dice_roll)
+            print("board:")
+            print(self.board)
+        elif self.render_mode in ("human", "rgb_array"):
+            raise DependencyNotInstalled("pygame rendering (envs/ewn.py:503-569) is out of scope of the HIP engine")
+
+    def close(self):
+        pass

@@ -1,0 +1,64 @@
+"""Host-side API surface of the drop-in packages (no GPU): names, signatures, enums."""
+import inspect
+
+import pytest
+
+
+def test_constants():
+    from constants import ClassicalPolicy, Player
+    assert [p.value for p in Player] == [1, 2, 3]
+    assert Player.get_opponent(Player.TOP_LEFT) == Player.BOTTOM_RIGHT
+    assert Player.get_opponent(Player.BOTTOM_RIGHT) == Player.TOP_LEFT
+    with pytest.raises(ValueError):
+        Player.get_opponent(Player.CHANCE)
+    assert [p.value for p in ClassicalPolicy] == ["random", "minimax", "uct", "alpha_zero", "mcts"]
+    assert str(ClassicalPolicy.minimax) == "minimax"
+    assert ClassicalPolicy.from_string("mcts") is ClassicalPolicy.mcts
+    assert ClassicalPolicy.from_string("models/best.zip") == "models/best.zip"   # checkpoint-path quirk
+
+
+def _params(f):
+    return list(inspect.signature(f).parameters)
+
+
+def test_constructor_signatures_match_the_reference():
+    import classical_policies as cp
+    import envs
+    # envs/ewn.py:35-42
+    assert _params(envs.EinsteinWuerfeltNichtEnv.__init__)[:8] == [
+        "self", "board_size", "cube_layer", "seed", "reward", "agent_player", "render_mode", "opponent_policy"]
+    sig = inspect.signature(envs.EinsteinWuerfeltNichtEnv.__init__).parameters
+    assert (sig["board_size"].default, sig["cube_layer"].default, sig["seed"].default, sig["reward"].default) == (5, 3, 9487, 1.)
+    # envs/training_ewn.py:19-29
+    p = inspect.signature(envs.MiniMaxHeuristicEnv.__init__).parameters
+    assert (p["goal_reward"].default, p["illegal_move_reward"].default, p["illegal_move_tolerance"].default) == (10., -1.0, 10)
+    # classical_policies/minimax.py:10-11, mcts.py:11-13, random_policy.py:7
+    assert _params(cp.ExpectiMinimaxAgent.__init__)[:5] == ["self", "max_depth", "cube_layer", "board_size", "heuristic"]
+    assert _params(cp.MctsAgent.__init__)[:5] == ["self", "cube_layer", "board_size", "num_simulations", "num_env_copies"]
+    m = inspect.signature(cp.MctsAgent.__init__).parameters
+    assert (m["num_simulations"].default, m["num_env_copies"].default) == (10, 5)
+    assert _params(cp.RandomAgent.__init__) == ["self", "env"]
+    for cls in (cp.RandomAgent, cp.ExpectiMinimaxAgent, cp.MctsAgent):
+        assert issubclass(cls, cp.PolicyBase) and _params(cls.predict)[:2] == ["self", "obs"]
+    assert _params(envs.EinsteinWuerfeltNichtEnv.reset) == ["self", "seed"]   # no `options` kwarg upstream
+    for name in ("step", "render", "close", "get_legal_actions", "check_win", "find_cube_to_move", "switch_player"):
+        assert hasattr(envs.EinsteinWuerfeltNichtEnv, name)
+    assert hasattr(envs.MinimaxEnv, "set_dice_roll") and hasattr(envs.MinimaxEnv, "evaluate")
+
+
+def test_out_of_scope_agents_say_so():
+    import classical_policies as cp
+    with pytest.raises(NotImplementedError):
+        cp.AlphaZeroAgent(cube_layer=3, board_size=5)
+    with pytest.raises(NotImplementedError):
+        cp.AlphaZeroMinimaxAgent(3, 3, 5)
+
+
+def test_spaces_compat():
+    from ewn_gym_amd import spaces_compat as sp
+    md = sp.MultiDiscrete([2, 3])
+    md.seed(1)
+    for _ in range(20):
+        assert md.contains(md.sample())
+    d = sp.Discrete(7, start=1)
+    assert d.contains(1) and d.contains(7) and not d.contains(0) and not d.contains(8)

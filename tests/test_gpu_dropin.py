@@ -1,0 +1,149 @@
+"""The drop-in packages (`envs`, `classical_policies`, `constants`) driven the way the
+reference's own scripts drive them (eval_minimax.py:16-50: reset(seed=k), predict, step),
+against the golden trajectories captured from the reference."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _replay(env, rec):
+    obs, info = env.reset(seed=rec["seed"])
+    assert info == {} and obs["board"].reshape(-1).tolist() == rec["board0"] and obs["dice_roll"] == rec["dice0"]
+    assert obs["board"] is env.board and obs["board"].dtype == np.int16   # live alias, int16: envs/ewn.py:49,493
+    for t, st in enumerate(rec["steps"]):
+        obs, reward, terminated, truncated, info = env.step(np.array(st["a"]))
+        ctx = (rec["seed"], t)
+        assert obs["board"].reshape(-1).tolist() == st["board"], ctx
+        assert obs["dice_roll"] == st["dice"], ctx
+        assert float(reward).hex() == float.fromhex(st["r"]).hex(), ctx
+        assert (terminated, truncated) == (st["term"], st["trunc"]), ctx
+        assert info.get("message") == st["msg"], ctx
+
+
+def test_env_random_opponent_trajectories(golden):
+    import envs
+    from constants import ClassicalPolicy
+    g = [r for r in golden("g3_traj_random.json") if r["S"] <= 8]
+    for (S, L) in sorted({(r["S"], r["L"]) for r in g}):
+        env = envs.EinsteinWuerfeltNichtEnv(board_size=S, cube_layer=L, opponent_policy=ClassicalPolicy.random)
+        assert type(env.opponent_policy).__name__ == "RandomAgent"
+        for rec in [r for r in g if (r["S"], r["L"]) == (S, L)][:24]:
+            _replay(env, rec)
+
+
+def test_env_minimax_opponent_trajectories(golden):
+    import envs
+    from constants import ClassicalPolicy
+    g = golden("g6_traj_minimax.json")
+    for key in sorted({(r["S"], r["L"], r["depth"], r["heuristic"]) for r in g}):
+        S, L, depth, heur = key
+        env = envs.EinsteinWuerfeltNichtEnv(board_size=S, cube_layer=L, opponent_policy=ClassicalPolicy.minimax,
+                                            max_depth=depth, heuristic=heur)
+        for rec in [r for r in g if (r["S"], r["L"], r["depth"], r["heuristic"]) == key][:6]:
+            _replay(env, rec)
+    with pytest.raises(TypeError):   # max_depth is a required argument of ExpectiMinimaxAgent upstream too
+        envs.EinsteinWuerfeltNichtEnv(opponent_policy=ClassicalPolicy.minimax)
+
+
+def test_training_env_with_reference_quirks(golden):
+    import envs
+    from constants import ClassicalPolicy
+    for grp in golden("g7_shaped.json"):
+        env = envs.MiniMaxHeuristicEnv(board_size=5, cube_layer=3, illegal_move_tolerance=grp["tol"],
+                                       opponent_policy=ClassicalPolicy.minimax, goal_reward=10., seed=123)
+        assert type(env.opponent_policy).__name__ == grp["opp_class"]          # D1: RandomAgent despite the argument
+        assert float(env.reward).hex() == grp["ctor_reward"]
+        assert float(env.prev_score).hex() == float.fromhex(grp["ctor_prev_score"]).hex()
+        for rec in grp["episodes"]:
+            _replay(env, rec)
+            assert env.illegal_move_tolerance == rec["tol_after"]
+            assert float(env.prev_score).hex() == float.fromhex(rec["prev_score_after"]).hex()
+
+
+def test_intended_behaviour_without_quirks():
+    import envs
+    from constants import ClassicalPolicy
+    env = envs.MiniMaxHeuristicEnv(opponent_policy=ClassicalPolicy.minimax, max_depth=3, goal_reward=10., seed=5,
+                                   reference_quirks=False)
+    assert type(env.opponent_policy).__name__ == "ExpectiMinimaxAgent" and env.reward == 10.0
+    obs, _ = env.reset(seed=5)
+    done, n = False, 0
+    while not done and n < 100:
+        a = env.get_legal_actions(env.current_player)[0]
+        obs, r, done, trunc, info = env.step(a)
+        n += 1
+    assert done and abs(r) == 10.0
+
+
+def test_policies_predict_like_the_reference(golden):
+    from classical_policies import ExpectiMinimaxAgent, MctsAgent, RandomAgent, MiniMaxPolicy
+    assert MiniMaxPolicy is ExpectiMinimaxAgent
+    g = [r for r in golden("g5_minimax.json") if r["S"] == 5]
+    agents = {}
+    for r in g[:40]:
+        board = np.array(r["board"], np.int16).reshape(5, 5)
+        for key, (a0, a1, v) in r["res"].items():
+            d, h = key.split("/")
+            ag = agents.setdefault(key, ExpectiMinimaxAgent(int(d), 3, 5, heuristic=h))
+            action, state = ag.predict({"board": board, "dice_roll": r["dice"]}, deterministic=True)
+            assert state is None and isinstance(action, list) and action == [a0, a1]
+            val, act = ag.expectiminimax_root({"board": board, "dice_roll": r["dice"]})
+            assert val.hex() == float.fromhex(v).hex()
+    board = np.array(g[0]["board"], np.int16).reshape(5, 5)
+    m = MctsAgent(3, 5, num_simulations=10, num_env_copies=5)
+    action, state = m.predict({"board": board, "dice_roll": g[0]["dice"]})
+    assert state is None and isinstance(action, np.ndarray) and action.shape == (2,)
+    import envs
+    env = envs.EinsteinWuerfeltNichtEnv()
+    ra = RandomAgent(env)
+    obs, _ = env.reset(seed=3)
+    for _ in range(5):
+        action, _ = ra.predict(obs)
+        assert action.tolist() in env.get_legal_actions(env.current_player)
+
+
+def test_env_queries(golden):
+    import envs
+    from constants import Player
+    env = envs.MinimaxEnv()
+    g = [r for r in golden("g2_legal.json") if (r["S"], r["L"]) == (5, 3)][:120]
+    for r in g:
+        env.board[:] = np.array(r["board"]).reshape(5, 5)
+        env.set_dice_roll(r["dice"])
+        assert env.check_win() == r["win"]
+        if "legal" in r:
+            pl = Player(r["player"])
+            assert env.get_legal_actions(pl) == r["legal"]
+            idx = env.find_cube_to_move(True, pl)
+            assert (idx + 1 if pl == Player.TOP_LEFT else -idx) == r["cube_large"]
+            cp = env.cube_pos
+            for (i, j), c in np.ndenumerate(env.board):
+                if c != 0:
+                    k = c - 1 if c > 0 else c
+                    assert tuple(cp[k]) == (i, j)
+    g4 = [r for r in golden("g4_eval.json") if (r["S"], r["L"]) == (5, 3)][:60]
+    for r in g4:
+        env.board[:] = np.array(r["board"]).reshape(5, 5)
+        for h in ("hybrid", "min_dist", "two_min_dist", "attk"):
+            assert float(env.evaluate(h)).hex() == float.fromhex(r[h]).hex()
+    with pytest.raises(ValueError):
+        env.get_legal_actions(Player.CHANCE)
+    with pytest.raises(AssertionError):
+        envs.EinsteinWuerfeltNichtEnv(board_size=5, cube_layer=4)
+
+
+def test_ansi_render(capsys):
+    import envs
+    env = envs.EinsteinWuerfeltNichtEnv(render_mode="ansi")
+    env.reset(seed=0)
+    env.render()
+    out = capsys.readouterr().out
+    assert out.startswith("dice:\n5\nboard:\n")
