@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libewn_hip.so")
+LIB_PATH = os.environ.get("EWN_HIP_LIB", os.path.join(HERE, "lib", "libewn_hip.so"))  # override: A/B builds while profiling
 
 OPP = {"random": 0, "minimax": 1, "mcts": 2}
 RNG = {"mt19937": 0, "philox": 1}
