@@ -5,8 +5,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", "ewn_kernels.hip")]
-DEPS = SRC + [os.path.join(HERE, "csrc", "ewn_core.hpp"), os.path.join(HERE, "csrc", "ewn_fast.hpp"),
-              os.path.join(HERE, "..", "include", "ewn_hip.h")]
+DEPS = [os.path.join(HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(HERE, "csrc")))] + \
+       [os.path.join(HERE, "..", "include", "ewn_hip.h")]
 OUT = os.path.join(HERE, "lib", "libewn_hip.so")
 # -ffp-contract=off: the fp64 heuristic and expectation sums must round exactly like the
 # reference's Python floats (no FMA contraction); no fast-math anywhere.

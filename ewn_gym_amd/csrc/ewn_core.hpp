@@ -21,6 +21,9 @@ struct Geom {
     u64 not_lastcol, not_lastrow, not_firstcol, not_firstrow, corner_br;
     u64 sq[8];          // sq[t] = cells with row >= t and col >= t  (distance to the bottom-right corner <= S-1-t)
     int8_t init[64];    // initial board, envs/ewn.py:94-107
+    // the same position already decoded (GState layout), so reset() copies registers instead of scanning cells
+    u64 init_occP, init_occN, init_posP[2], init_posN[2];
+    u32 init_alive;
 };
 
 // SIDE 0 = TOP_LEFT (positive numbers), SIDE 1 = BOTTOM_RIGHT (negative numbers).
@@ -77,6 +80,13 @@ EWN_DEV void encode_board(const Geom &g, const GState<NW> &s, BytePtr b)
         if ((s.aliveP >> k) & 1u) b[pos_get<NW>(s.posP, k)] = (int8_t)(k + 1);
         if ((s.aliveN >> k) & 1u) b[pos_get<NW>(s.posN, k)] = (int8_t)(-(k + 1));
     }
+}
+
+template <int NW>
+EWN_DEV void init_state(const Geom &g, GState<NW> &s)
+{
+    s.occP = g.init_occP; s.occN = g.init_occN; s.aliveP = s.aliveN = g.init_alive;
+    for (int w = 0; w < NW; w++) { s.posP[w] = g.init_posP[w]; s.posN[w] = g.init_posN[w]; }
 }
 
 // opponent_action's np.rot90(-board, 2) (envs/ewn.py:294): swap sides, mirror every cell index.
@@ -358,21 +368,26 @@ __device__ __noinline__ u32 mt_output_closed(u32 seed, u32 n)
     return mt_temper(x397 ^ mt_twist(sn, sn1));
 }
 
-#define EWN_RNG_HDR 4 // words: seed, draw index, next_seed, flags(bit0 = MT draw index >= 454: unsupported)
+#define EWN_RNG_HDR 4 // header words per lane: seed, draw index, next_seed, flags(bit0 = MT draw index >= 454: unsupported)
+
+// ewn_state.rng holds N headers (uint4 each, one coalesced 16-byte access per lane) followed by
+// N windows of W tempered MT19937 outputs (MT kind only).
+EWN_DEV uint4 *rng_hdr_ptr(u32 *rng, int lane) { return (uint4 *)rng + lane; }
+EWN_DEV u32 *rng_win_ptr(u32 *rng, int N, u32 W, int lane) { return rng + (size_t)N * EWN_RNG_HDR + (size_t)lane * W; }
 
 // One lane's dice stream for the duration of a kernel.
 struct LaneRng {
     int kind;         // 0 MT19937 window, 1 Philox
-    u32 seed, n, flags;
+    u32 seed, n, next_seed, flags;
     u32 W;
     const u32 *win;
     PhiloxStream ps;
-    EWN_DEV void load(int kind_, const u32 *hdr, u32 W_, u64 key)
+    EWN_DEV void load(int kind_, uint4 h, const u32 *win_, u32 W_, u64 key)
     {
-        kind = kind_; seed = hdr[0]; n = hdr[1]; flags = hdr[3]; W = W_; win = hdr + EWN_RNG_HDR;
+        kind = kind_; seed = h.x; n = h.y; next_seed = h.z; flags = h.w; W = W_; win = win_;
         if (kind == 1) ps.init(seed, 0u, 0x454E5631u, key, n);
     }
-    EWN_DEV void store(u32 *hdr) const { hdr[1] = kind == 1 ? ps.n : n; hdr[3] = flags; }
+    EWN_DEV uint4 header() const { return make_uint4(seed, kind == 1 ? ps.n : n, next_seed, flags); }
     EWN_DEV u32 draws() const { return kind == 1 ? ps.n : n; }
     EWN_DEV u32 next()
     {

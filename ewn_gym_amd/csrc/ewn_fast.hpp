@@ -42,7 +42,13 @@ struct FastTab {
     uint8_t nbp[3][64];                          // mover   (TOP_LEFT):     ring index -> destination ring index, 255 = off board
     uint8_t nbn[3][64];                          // replier (BOTTOM_RIGHT): ring index -> destination ring index, 255 = off board
     int32_t nv, ri_origin, pad0, pad1;           // number of ranks; ring index of cell (0,0)
+    // for the fused step kernel (ewn_step_d3.hpp), which keeps the game in canonical ring space:
+    uint8_t real_of_ring[64];                    // ring index -> REAL row-major cell (canonical cell = S*S-1 - real cell)
+    uint64_t init_P, init_N, init_posP, init_posN; // the start position (envs/ewn.py:94-107): opponent = P side, agent = N side
 };
+
+// LDS / device image size: the struct padded to 4 KiB so the LDS-DMA copy needs no tail handling
+#define FAST_TAB_BYTES(S) ((int)((sizeof(FastTab<S>) + 4095) / 4096 * 4096))
 
 template <int S> struct MaskOf { typedef u32 type; };
 template <> struct MaskOf<6> { typedef u64 type; };
@@ -97,8 +103,7 @@ __device__ __forceinline__ double fast_d3(const FastTab<S> *T, const GState<1> &
     const int flag0 = cs.exact ? 0 : 1;
     const int rp0 = T->ri[pos_get<1>(c.posP, have0 ? k0 : 0)], rp1 = T->ri[pos_get<1>(c.posP, have1 ? k1 : 0)];
 
-    double best = -__builtin_inf();
-    int A = -1;       // rank threshold: leaf value <= alpha  <=>  rank <= A
+    double best = -__builtin_inf(); // alpha = max(alpha, best_val) is simply the running best (root beta stays +inf)
     bflag = 0; bdir = 0;
 
     #pragma unroll
@@ -110,72 +115,60 @@ __device__ __forceinline__ double fast_d3(const FastTab<S> *T, const GState<1> &
         const M bd = valid ? (one << dest) : (M)0;
         const M P1 = (P & ~(one << rp)) | bd; // own capture: the bit is already set, the count drops by itself
         const M N1 = N & ~bd;
-        double v;
-        if (dest == FastTab<S>::CELLS - 1 || N1 == 0) {
-            v = 10.0; // win(B1): evaluate(B1), envs/minimax_ewn.py:42-44
-        } else {
-            // leaves of this root: replier cube k (alive in B1) x dir -> packed prefix minima of ranks
-            u32 tr[6];
+        // win(B1): evaluate(B1) = 10, envs/minimax_ewn.py:42-44.  The leaf work below runs regardless
+        // (predicated, no branch) so the scheduler can overlap the LDS reads of all 18 leaves.
+        const bool term = dest == FastTab<S>::CELLS - 1 || N1 == 0;
+        // leaves of this root: replier cube k (alive in B1) x dir -> packed prefix minima of ranks
+        u32 tr[6];
+        #pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const bool alive1 = ((c.aliveN >> k) & 1u) && rn[k] != dest;
+            const M Nk = N1 & rclr[k];
+            u32 a[3];
             #pragma unroll
-            for (int k = 0; k < 6; k++) {
-                const bool alive1 = ((c.aliveN >> k) & 1u) && rn[k] != dest;
-                const M Nk = N1 & rclr[k];
-                u32 a[3];
-                #pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    const M N2 = Nk | rset[k][d];
-                    const M P2 = P1 & ~rset[k][d];
-                    const int ix = T->lutx[clz_m(P2)] + popc_m(P2) * IXN;
-                    const int iy = T->luty[clz_m(N2)] + popc_m(N2);
-                    u32 rk = T->rank[ix + iy];
-                    rk = (P2 == 0 || ((hits_origin >> (k * 3 + d)) & 1u)) ? 0u : rk;   // -10: envs/minimax_ewn.py:45-47
-                    a[d] = (alive1 && ((legal >> (k * 3 + d)) & 1u)) ? rk : 1023u;
-                }
-                const u32 p1 = min(a[0], a[1]), p2 = min(p1, a[2]);
-                tr[k] = a[0] | (p1 << 10) | (p2 << 20);
+            for (int d = 0; d < 3; d++) {
+                const M N2 = Nk | rset[k][d];
+                const M P2 = P1 & ~rset[k][d];
+                const int ix = T->lutx[clz_m(P2)] + popc_m(P2) * IXN;
+                const int iy = T->luty[clz_m(N2)] + popc_m(N2);
+                u32 rk = T->rank[ix + iy];
+                rk = (P2 == 0 || ((hits_origin >> (k * 3 + d)) & 1u)) ? 0u : rk;   // -10: envs/minimax_ewn.py:45-47
+                a[d] = (alive1 && ((legal >> (k * 3 + d)) & 1u)) ? rk : 1023u;
             }
-            // which cubes a dice value selects (find_near_cube): carry the nearest alive cube's data along
-            u32 upT[6], downT[6];
-            {
-                u32 cur = FAST_NONE;
-                #pragma unroll
-                for (int d = 5; d >= 0; d--) { upT[d] = cur; cur = tr[d] != FAST_NONE ? tr[d] : cur; }
-                cur = FAST_NONE;
-                #pragma unroll
-                for (int d = 0; d < 6; d++) { downT[d] = cur; cur = tr[d] != FAST_NONE ? tr[d] : cur; }
-            }
-            v = 0.0;
-            #pragma unroll
-            for (int d = 0; d < 6; d++) {
-                const bool exact = tr[d] != FAST_NONE;
-                const bool up = upT[d] != FAST_NONE;
-                const u32 F = exact ? tr[d] : (up ? upT[d] : downT[d]);
-                const u32 G = (!exact && up) ? downT[d] : FAST_NONE;
-                const int x0 = (int)(F & 1023u), x1 = (int)((F >> 10) & 1023u), x2 = (int)(F >> 20);
-                const int y0 = min(x2, (int)(G & 1023u)), y1 = min(x2, (int)((G >> 10) & 1023u)), y2 = min(x2, (int)(G >> 20));
-                int w = y2; // the full minimum: what the loop returns when it never breaks
-                w = max(w, x0 <= A ? x0 : 0);
-                w = max(w, x1 <= A ? x1 : 0);
-                w = max(w, x2 <= A ? x2 : 0);
-                w = max(w, y0 <= A ? y0 : 0);
-                w = max(w, y1 <= A ? y1 : 0);
-                v = v + T->val6[w]; // expected_val += val / 6, minimax.py:72
-            }
+            const u32 p1 = min(a[0], a[1]), p2 = min(p1, a[2]);
+            tr[k] = a[0] | (p1 << 10) | (p2 << 20);
         }
+        // which cubes a dice value selects (find_near_cube): carry the nearest alive cube's data along
+        u32 upT[6], downT[6];
+        {
+            u32 cur = FAST_NONE;
+            #pragma unroll
+            for (int d = 5; d >= 0; d--) { upT[d] = cur; cur = tr[d] != FAST_NONE ? tr[d] : cur; }
+            cur = FAST_NONE;
+            #pragma unroll
+            for (int d = 0; d < 6; d++) { downT[d] = cur; cur = tr[d] != FAST_NONE ? tr[d] : cur; }
+        }
+        double v = 0.0;
+        #pragma unroll
+        for (int d = 0; d < 6; d++) {
+            const bool exact = tr[d] != FAST_NONE;
+            const bool up = upT[d] != FAST_NONE;
+            const u32 F = exact ? tr[d] : (up ? upT[d] : downT[d]);
+            const u32 G = (!exact && up) ? downT[d] : FAST_NONE;
+            const int x0 = (int)(F & 1023u), x1 = (int)((F >> 10) & 1023u), x2 = (int)(F >> 20);
+            const int y0 = min(x2, (int)(G & 1023u)), y1 = min(x2, (int)((G >> 10) & 1023u)), y2 = min(x2, (int)(G >> 20));
+            // `worst <= alpha` (minimax.py:59-61) against alpha = best so far; val[1023] = +inf marks "no such reply"
+            int w = y2; // the full minimum: what the loop returns when it never breaks
+            w = max(w, T->val[x0] <= best ? x0 : 0);
+            w = max(w, T->val[x1] <= best ? x1 : 0);
+            w = max(w, T->val[x2] <= best ? x2 : 0);
+            w = max(w, T->val[y0] <= best ? y0 : 0);
+            w = max(w, T->val[y1] <= best ? y1 : 0);
+            v = v + T->val6[w]; // expected_val += val / 6, minimax.py:72
+        }
+        v = term ? 10.0 : v;
         if (valid && v > best) {
             best = v; bflag = slot == 0 ? flag0 : 0; bdir = dir;
-        }
-        if (r < 5) {
-            // alpha = max(alpha, best): largest rank whose value is <= best (val[] ascending); -1 if none
-            int lo = -1, hi = T->nv - 1;
-            #pragma unroll 1
-            for (int it = 0; it < 10; it++) {
-                const int mid = (lo + hi + 1) >> 1;
-                const bool le = T->val[max(mid, 0)] <= best;
-                lo = le ? mid : lo;
-                hi = le ? hi : mid - 1;
-            }
-            A = lo;
         }
     }
     return best;
@@ -210,6 +203,18 @@ static int build_fast_tables(FastTab<S> *T)
             if (i + di < S && j + dj < S) T->nbp[d][q] = (uint8_t)ring_of_rm[(i + di) * S + (j + dj)];
             if (i - di >= 0 && j - dj >= 0) T->nbn[d][q] = (uint8_t)ring_of_rm[(i - di) * S + (j - dj)];
         }
+    for (int q = 0; q < 64; q++) T->real_of_ring[q] = q < S * S ? (uint8_t)(S * S - 1 - rm_of_ring[q]) : 0;
+    {
+        int cnt = 1;
+        for (int i = 1; i <= 3; i++)
+            for (int j = 0; j < i; j++) {
+                const int cpos = j * S + (i - j - 1), cneg = (S - 1 - j) * S + (S - i + j); // real cells of +cnt / -cnt
+                const int rN = ring_of_rm[S * S - 1 - cpos], rP = ring_of_rm[S * S - 1 - cneg];
+                T->init_N |= 1ull << rN; T->init_posN |= (uint64_t)rN << (6 * (cnt - 1));
+                T->init_P |= 1ull << rP; T->init_posP |= (uint64_t)rP << (6 * (cnt - 1));
+                cnt++;
+            }
+    }
     const int W = S <= 5 ? 32 : 64;
     for (int z = 0; z <= W; z++) {
         const int h = W - 1 - z; // highest set bit
@@ -238,7 +243,7 @@ static int build_fast_tables(FastTab<S> *T)
     if ((int)all.size() > FAST_NV - 1) return -1;
     T->nv = (int)all.size();
     for (int i = 0; i < FAST_NV; i++) {
-        const double v = i < T->nv ? all[i] : all.back();
+        const double v = i < T->nv ? all[i] : __builtin_inf(); // unused ranks compare above every alpha
         volatile double q = v / 6.0;
         T->val[i] = v; T->val6[i] = q;
     }

@@ -9,6 +9,7 @@
 #include "ewn_core.hpp"
 #include "ewn_fast.hpp"
 #include "../../include/ewn_hip.h"
+#include <cstdlib>
 
 #define BS 256
 
@@ -33,32 +34,55 @@ struct KScratch { // split-phase step (MCTS opponent)
 
 // ---------------------------------------------------------------- LDS staging
 
-// Copy nbytes between global and LDS with the whole block: dwords when both sides are
-// 4-byte aligned (consecutive threads -> consecutive dwords), bytes for the tail.
+// Copy nbytes between global and LDS with the whole block: 16-byte vectors when both
+// sides allow it (consecutive threads -> consecutive 16-byte pieces), then dwords, then
+// the byte tail.  All loads of a pass are issued before the first LDS store.
 __device__ __forceinline__ void block_copy_in(int8_t *lds, const int8_t *g, int nbytes)
 {
-    const int nw = (((uintptr_t)g & 3) == 0) ? nbytes >> 2 : 0;
-    for (int i = threadIdx.x; i < nw; i += blockDim.x) ((u32 *)lds)[i] = ((const u32 *)g)[i];
+    const int nq = (((uintptr_t)g & 15) == 0) ? nbytes >> 4 : 0;
+    for (int i = threadIdx.x; i < nq; i += blockDim.x) ((uint4 *)lds)[i] = ((const uint4 *)g)[i];
+    const int w0 = nq << 2, nw = (((uintptr_t)g & 3) == 0) ? nbytes >> 2 : w0;
+    for (int i = w0 + threadIdx.x; i < nw; i += blockDim.x) ((u32 *)lds)[i] = ((const u32 *)g)[i];
     for (int i = (nw << 2) + threadIdx.x; i < nbytes; i += blockDim.x) lds[i] = g[i];
 }
 
 __device__ __forceinline__ void block_copy_out(int8_t *g, const int8_t *lds, int nbytes)
 {
-    const int nw = (((uintptr_t)g & 3) == 0) ? nbytes >> 2 : 0;
-    for (int i = threadIdx.x; i < nw; i += blockDim.x) ((u32 *)g)[i] = ((const u32 *)lds)[i];
+    const int nq = (((uintptr_t)g & 15) == 0) ? nbytes >> 4 : 0;
+    for (int i = threadIdx.x; i < nq; i += blockDim.x) ((uint4 *)g)[i] = ((const uint4 *)lds)[i];
+    const int w0 = nq << 2, nw = (((uintptr_t)g & 3) == 0) ? nbytes >> 2 : w0;
+    for (int i = w0 + threadIdx.x; i < nw; i += blockDim.x) ((u32 *)g)[i] = ((const u32 *)lds)[i];
     for (int i = (nw << 2) + threadIdx.x; i < nbytes; i += blockDim.x) g[i] = lds[i];
 }
+
+// Search tables, global -> LDS with the LDS-DMA form of the load (global_load_lds_dwordx4):
+// no VGPR staging and nothing waits on it until the barrier in front of the search.
+// BYTES is a multiple of 4096 (256 threads x 16 B); src 16-byte aligned; dst = wave-uniform
+// base + lane*16, which is exactly the linear image we want.
+template <int BYTES>
+__device__ __forceinline__ void tables_to_lds(int8_t *lds, const int8_t *g)
+{
+    static_assert(BYTES % (BS * 16) == 0, "table size must be padded to 4 KiB");
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    #pragma unroll
+    for (int cnk = 0; cnk < BYTES / (BS * 16); cnk++) {
+        const int off = (cnk * (BS / 64) + wave) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + off + lane * 16),
+                                         (__attribute__((address_space(3))) void *)(lds + off), 16, 0, 0);
+    }
+}
+
+#include "ewn_step_d3.hpp"
 
 // ---------------------------------------------------------------- per-lane pieces
 
 // reset(seed) + setup_game, envs/ewn.py:488-494, 94-108
 template <int NW>
-__device__ void lane_reset(const Geom &g, const KCfg &c, u32 seed, u32 *hdr, GState<NW> &s, int &dice, LaneRng &r)
+__device__ void lane_reset(const Geom &g, const KCfg &c, u32 seed, u32 *win, GState<NW> &s, int &dice, LaneRng &r)
 {
-    hdr[0] = seed; hdr[1] = 0; hdr[2] = seed + c.seed_stride; hdr[3] = 0;
-    if (c.rng_kind == 0) mt_fill_window(seed, (int)c.W, hdr + EWN_RNG_HDR);
-    r.load(c.rng_kind, hdr, c.W, c.key);
-    decode_board<NW>(g, g.init, s);
+    if (c.rng_kind == 0) mt_fill_window(seed, (int)c.W, win);
+    r.load(c.rng_kind, make_uint4(seed, 0u, seed + c.seed_stride, 0u), win, c.W, c.key);
+    init_state<NW>(g, s);
     dice = r.randint(1, g.CN + 1); // roll_dice :90-91
 }
 
@@ -147,16 +171,16 @@ __device__ void policy_minimax_rt(const Geom &g, const GState<NW> &s, int dice, 
 template <int NW>
 __global__ __launch_bounds__(BS) void k_reset(Geom g, KCfg c, KState st, const u32 *seeds, const uint8_t *mask)
 {
-    extern __shared__ int8_t lds[];
+    extern __shared__ __attribute__((aligned(16))) int8_t lds[];
     const int lane0 = blockIdx.x * BS, nl = min(BS, c.N - lane0), lane = lane0 + threadIdx.x;
     block_copy_in(lds, st.board + (size_t)lane0 * g.cells, nl * g.cells);
     __syncthreads();
     if (lane < c.N && (!mask || mask[lane])) {
-        u32 *hdr = st.rng + (size_t)lane * c.rng_words;
-        const u32 seed = seeds ? seeds[lane] : hdr[2];
+        uint4 *hp = rng_hdr_ptr(st.rng, lane);
+        const u32 seed = seeds ? seeds[lane] : hp->z;
         GState<NW> s; int dice; LaneRng r;
-        lane_reset<NW>(g, c, seed, hdr, s, dice, r);
-        r.store(hdr);
+        lane_reset<NW>(g, c, seed, rng_win_ptr(st.rng, c.N, c.W, lane), s, dice, r);
+        *hp = r.header();
         st.dice[lane] = (int8_t)dice;
         st.done[lane] = 0;
         if (c.shaped && c.refresh && st.prev_score) st.prev_score[lane] = evaluate<NW>(g, s, EWN_H_HYBRID);
@@ -172,11 +196,10 @@ __global__ __launch_bounds__(BS) void k_init_aux(Geom g, KCfg c, KState st, int 
     const int lane = blockIdx.x * BS + threadIdx.x;
     if (lane >= c.N) return;
     st.done[lane] = 0;
-    u32 *hdr = st.rng + (size_t)lane * c.rng_words;
-    hdr[0] = hdr[1] = hdr[2] = hdr[3] = 0;
+    *rng_hdr_ptr(st.rng, lane) = make_uint4(0u, 0u, 0u, 0u);
     if (st.prev_score) {
         GState<NW> s;
-        decode_board<NW>(g, g.init, s);
+        init_state<NW>(g, s);
         st.prev_score[lane] = evaluate<NW>(g, s, EWN_H_HYBRID); // training_ewn.py:35
     }
     if (st.tolerance) st.tolerance[lane] = tol0;
@@ -194,51 +217,56 @@ __global__ __launch_bounds__(BS) void k_step(Geom g, KCfg c, KState st, const in
 {
     extern __shared__ __attribute__((aligned(16))) int8_t lds[];
     int8_t *lds_t = lds + BS * g.cells; // terminal-observation staging
+    const int lane0 = blockIdx.x * BS, nl = min(BS, c.N - lane0), lane = lane0 + threadIdx.x;
+    const bool live = lane < c.N;
     [[maybe_unused]] const FastTab<(FAST ? FAST : 5)> *ftab = nullptr;
-    if constexpr (FAST != 0) {
+    if constexpr (FAST != 0) { // LDS-DMA, waited for only at the barrier below
         int8_t *tb = lds + ((2 * BS * g.cells + 15) & ~15);
-        block_copy_in(tb, (const int8_t *)st.tables, (int)sizeof(FastTab<(FAST ? FAST : 5)>));
+        tables_to_lds<FAST_TAB_BYTES(FAST ? FAST : 5)>(tb, (const int8_t *)st.tables);
         ftab = (const FastTab<(FAST ? FAST : 5)> *)tb;
     }
-    const int lane0 = blockIdx.x * BS, nl = min(BS, c.N - lane0), lane = lane0 + threadIdx.x;
+    // every per-lane input is requested up front so the round trips overlap
+    uint4 hdr = make_uint4(0u, 0u, 0u, 0u);
+    int dice = 1, aflag = 0, adir = 0;
+    bool frozen = false, pending = false;
+    if (live) {
+        hdr = *rng_hdr_ptr(st.rng, lane);
+        dice = st.dice[lane];
+        frozen = st.done[lane] != 0;
+        if (PHASE != 2) { const uint16_t a2 = ((const uint16_t *)actions)[lane]; aflag = (int8_t)(a2 & 0xff); adir = (int8_t)(a2 >> 8); }
+        else { pending = sc.phase[lane] != 0; const uint16_t a2 = ((const uint16_t *)sc.act)[lane]; aflag = (int8_t)(a2 & 0xff); adir = (int8_t)(a2 >> 8); }
+    }
     block_copy_in(lds, st.board + (size_t)lane0 * g.cells, nl * g.cells);
     if (PHASE == 2 && out.tboard) block_copy_in(lds_t, out.tboard + (size_t)lane0 * g.cells, nl * g.cells);
     __syncthreads();
-    if (lane < c.N) {
+    if (live) {
         int8_t *mine = lds + threadIdx.x * g.cells, *mine_t = lds_t + threadIdx.x * g.cells;
-        const bool frozen = st.done[lane] != 0;
-        const bool skip = PHASE == 2 && (frozen || sc.phase[lane] == 0); // settled by the pre phase
+        const bool skip = PHASE == 2 && (frozen || !pending); // settled by the pre phase
         if (!skip) {
-            int dice = st.dice[lane];
             StepRes o; o.reward = 0.0; o.term = 0; o.trunc = 0; o.info = EWN_INFO_NONE;
             bool settled = true; // this launch produces the lane's step result
             if (frozen) {
-                o.term = 1;
                 // no reference counterpart: stepping a finished game is undefined upstream; the lane stays put
+                o.term = 1;
                 if (PHASE == 1) sc.phase[lane] = 0;
                 if (out.tboard) for (int i = 0; i < g.cells; i++) mine_t[i] = mine[i];
                 if (out.tdice) out.tdice[lane] = (int8_t)dice;
             } else {
-                u32 *hdr = st.rng + (size_t)lane * c.rng_words;
-                LaneRng r; r.load(c.rng_kind, hdr, c.W, c.key);
+                u32 *win = rng_win_ptr(st.rng, c.N, c.W, lane);
+                LaneRng r; r.load(c.rng_kind, hdr, win, c.W, c.key);
                 GState<NW> s;
                 decode_board<NW>(g, mine, s);
                 bool reply;
-                int oflag = 0, odir = 0;
-                if (PHASE != 2) {
-                    reply = step_agent<NW>(g, c, s, dice, actions[2 * lane], actions[2 * lane + 1], r,
-                                           st.tolerance ? st.tolerance + lane : nullptr, o);
-                } else {
-                    reply = true;
-                    oflag = sc.act[2 * lane]; odir = sc.act[2 * lane + 1];
-                }
+                int oflag = aflag, odir = adir;
+                if (PHASE != 2) reply = step_agent<NW>(g, c, s, dice, aflag, adir, r, st.tolerance ? st.tolerance + lane : nullptr, o);
+                else reply = true;
                 if (PHASE == 1) {
                     sc.phase[lane] = reply ? 1 : 0;
                     if (reply) {
                         const GState<NW> cst = canonicalize<NW>(g, s);
                         encode_board<NW>(g, cst, sc.cboard + (size_t)lane * g.cells);
                         sc.cdice[lane] = (int8_t)dice;
-                        sc.obs_id[lane] = hdr[0] * 0x9E3779B1u + r.draws();
+                        sc.obs_id[lane] = r.seed * 0x9E3779B1u + r.draws();
                         settled = false;
                     }
                 } else if (reply) {
@@ -256,12 +284,12 @@ __global__ __launch_bounds__(BS) void k_step(Geom g, KCfg c, KState st, const in
                     if (out.tdice) out.tdice[lane] = (int8_t)dice;
                     if (o.term) {
                         if (c.autoreset) {
-                            lane_reset<NW>(g, c, hdr[2], hdr, s, dice, r);
+                            lane_reset<NW>(g, c, r.next_seed, win, s, dice, r);
                             if (c.shaped && c.refresh && st.prev_score) st.prev_score[lane] = evaluate<NW>(g, s, EWN_H_HYBRID);
                         } else st.done[lane] = 1;
                     }
                 }
-                r.store(hdr);
+                *rng_hdr_ptr(st.rng, lane) = r.header();
                 encode_board<NW>(g, s, mine);
                 st.dice[lane] = (int8_t)dice;
             }
@@ -338,7 +366,7 @@ __global__ __launch_bounds__(BS) void k_predict_minimax_fast(Geom g, int M, cons
                                                              int8_t *actions, double *values, const void *tables)
 {
     extern __shared__ __attribute__((aligned(16))) int8_t lds[];
-    block_copy_in(lds, (const int8_t *)tables, (int)sizeof(FastTab<S>));
+    tables_to_lds<FAST_TAB_BYTES(S)>(lds, (const int8_t *)tables);
     __syncthreads();
     const FastTab<S> *T = (const FastTab<S> *)lds;
     const int m = blockIdx.x * BS + threadIdx.x;
@@ -492,6 +520,13 @@ static bool make_geom(int S, int L, Geom &g)
             g.init[(S - 1 - j) * S + (S - i + j)] = (int8_t)(-cnt);
             cnt++;
         }
+    g.init_occP = g.init_occN = 0; g.init_alive = 0;
+    for (int w = 0; w < 2; w++) g.init_posP[w] = g.init_posN[w] = 0;
+    for (int c = 0; c < S * S; c++) {
+        const int v = g.init[c];
+        if (v > 0) { g.init_occP |= 1ull << c; g.init_alive |= 1u << (v - 1); g.init_posP[(v - 1) / 10] |= (u64)c << (6 * ((v - 1) % 10)); }
+        if (v < 0) { g.init_occN |= 1ull << c; g.init_posN[(-v - 1) / 10] |= (u64)c << (6 * ((-v - 1) % 10)); }
+    }
     return true;
 }
 
@@ -531,12 +566,26 @@ static int64_t fast_tables_bytes(int S, int L)
 {
     if (L != 3) return 0;
     switch (S) {
-    case 5: return (int64_t)sizeof(FastTab<5>);
-    case 6: return (int64_t)sizeof(FastTab<6>);
-    case 7: return (int64_t)sizeof(FastTab<7>);
-    case 8: return (int64_t)sizeof(FastTab<8>);
+    case 5: return (int64_t)FAST_TAB_BYTES(5);
+    case 6: return (int64_t)FAST_TAB_BYTES(6);
+    case 7: return (int64_t)FAST_TAB_BYTES(7);
+    case 8: return (int64_t)FAST_TAB_BYTES(8);
     default: return 0;
     }
+}
+
+// Lanes of one wavefront that share a game in k_step_d3: enough to put several waves on every SIMD
+// (1024 SIMDs x 64 lanes) at the given number of games.  EWN_D3_T=0 disables the kernel, 1/2/4 forces T.
+static int d3_threads_per_game(int n_games)
+{
+    static const int forced = [] { const char *e = getenv("EWN_D3_T"); return e ? atoi(e) : -1; }();
+    if (forced == 0 || forced == 1 || forced == 2 || forced == 4) return forced;
+    // measured on MI355X at 65 536 games (rocprofv3 kernel time): T=1 30.3 us, T=2 25.3 us, T=4 31.6 us.  The kernel is
+    // bound by integer VALU issue (one wave-instruction per 4 cycles per SIMD), so lanes added beyond what hides the
+    // LDS/global latency only add redundant instructions.
+    if (n_games >= 131072) return 1;
+    if (n_games >= 8192) return 2;
+    return 4;
 }
 
 #define GRID(n) dim3((unsigned)(((long long)(n) + BS - 1) / BS))
@@ -690,13 +739,32 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
     if (cfg->opponent_kind != EWN_OPP_MCTS) {
         const bool fast = st->tables && fast_tables_bytes(g.S, g.L) > 0 && cfg->opponent_kind == EWN_OPP_MINIMAX &&
                           cfg->max_depth == 3 && cfg->heuristic == EWN_H_HYBRID;
+        if (fast && !cfg->shaped && d3_threads_per_game(k.N) > 0) {
+            // the lean fused kernel: canonical ring space end to end, T lanes per game (ewn_step_d3.hpp)
+            const int T = d3_threads_per_game(k.N);
+            D3Cfg dc = { k.N, k.rng_kind, k.autoreset, k.seed_stride, k.W, k.reward, k.key };
+            D3Buf db = { st->board, st->dice, st->done, st->rng, st->tables, actions, out->reward, out->terminated,
+                         out->truncated, out->info, out->terminal_board, out->terminal_dice };
+            const int gpb = D3_BS / T;
+            const dim3 grid((unsigned)((k.N + gpb - 1) / gpb));
+            const size_t l3 = (((size_t)2 * gpb * g.cells + 15) & ~(size_t)15);
+#define D3_LAUNCH(SS, TT) k_step_d3<SS, TT><<<grid, D3_BS, l3 + FAST_TAB_BYTES(SS), s>>>(dc, db)
+#define D3_BY_T(SS) do { if (T == 1) D3_LAUNCH(SS, 1); else if (T == 2) D3_LAUNCH(SS, 2); else D3_LAUNCH(SS, 4); } while (0)
+            switch (g.S) {
+            case 5: D3_BY_T(5); break;
+            case 6: D3_BY_T(6); break;
+            case 7: D3_BY_T(7); break;
+            default: D3_BY_T(8); break;
+            }
+            return launch_status();
+        }
         if (fast) {
             const size_t base = (lds + 15) & ~(size_t)15;
             switch (g.S) {
-            case 5: k_step<1, 0, 5><<<GRID(k.N), BS, base + sizeof(FastTab<5>), s>>>(g, k, ks, actions, ko, sc); break;
-            case 6: k_step<1, 0, 6><<<GRID(k.N), BS, base + sizeof(FastTab<6>), s>>>(g, k, ks, actions, ko, sc); break;
-            case 7: k_step<1, 0, 7><<<GRID(k.N), BS, base + sizeof(FastTab<7>), s>>>(g, k, ks, actions, ko, sc); break;
-            default: k_step<1, 0, 8><<<GRID(k.N), BS, base + sizeof(FastTab<8>), s>>>(g, k, ks, actions, ko, sc); break;
+            case 5: k_step<1, 0, 5><<<GRID(k.N), BS, base + FAST_TAB_BYTES(5), s>>>(g, k, ks, actions, ko, sc); break;
+            case 6: k_step<1, 0, 6><<<GRID(k.N), BS, base + FAST_TAB_BYTES(6), s>>>(g, k, ks, actions, ko, sc); break;
+            case 7: k_step<1, 0, 7><<<GRID(k.N), BS, base + FAST_TAB_BYTES(7), s>>>(g, k, ks, actions, ko, sc); break;
+            default: k_step<1, 0, 8><<<GRID(k.N), BS, base + FAST_TAB_BYTES(8), s>>>(g, k, ks, actions, ko, sc); break;
             }
             return launch_status();
         }
@@ -767,10 +835,10 @@ int ewn_predict_minimax(int board_size, int cube_layer, int M, const int8_t *boa
     hipStream_t s = (hipStream_t)stream;
     if (tables && fast_tables_bytes(g.S, g.L) > 0 && max_depth == 3 && heuristic == EWN_H_HYBRID) {
         switch (g.S) {
-        case 5: k_predict_minimax_fast<5><<<GRID(M), BS, sizeof(FastTab<5>), s>>>(g, M, boards, dice, actions, values, tables); break;
-        case 6: k_predict_minimax_fast<6><<<GRID(M), BS, sizeof(FastTab<6>), s>>>(g, M, boards, dice, actions, values, tables); break;
-        case 7: k_predict_minimax_fast<7><<<GRID(M), BS, sizeof(FastTab<7>), s>>>(g, M, boards, dice, actions, values, tables); break;
-        default: k_predict_minimax_fast<8><<<GRID(M), BS, sizeof(FastTab<8>), s>>>(g, M, boards, dice, actions, values, tables); break;
+        case 5: k_predict_minimax_fast<5><<<GRID(M), BS, FAST_TAB_BYTES(5), s>>>(g, M, boards, dice, actions, values, tables); break;
+        case 6: k_predict_minimax_fast<6><<<GRID(M), BS, FAST_TAB_BYTES(6), s>>>(g, M, boards, dice, actions, values, tables); break;
+        case 7: k_predict_minimax_fast<7><<<GRID(M), BS, FAST_TAB_BYTES(7), s>>>(g, M, boards, dice, actions, values, tables); break;
+        default: k_predict_minimax_fast<8><<<GRID(M), BS, FAST_TAB_BYTES(8), s>>>(g, M, boards, dice, actions, values, tables); break;
         }
         return launch_status();
     }

@@ -1,0 +1,406 @@
+// ewn_step_d3.hpp -- the headline kernel: one fused env step with the depth-3 'hybrid'
+// expectiminimax opponent (BASELINE config: 5x5, cube_layer 3), lean and occupancy-aware.
+//
+// Differences from the generic k_step (ewn_kernels.hip), same results bit for bit:
+//  * the whole step lives in the opponent's CANONICAL view, ring-ordered (ewn_fast.hpp):
+//    the board bytes are decoded straight into that space with compile-time bit positions
+//    (real cell c -> canonical cell S*S-1-c -> ring index), so nothing is converted before
+//    the search.  The agent is the canonical BOTTOM_RIGHT side ("replier" geometry), the
+//    opponent the canonical TOP_LEFT side; an action [flag, dir] means the same in both
+//    views (envs/ewn.py:289-296);
+//  * T lanes cooperate on one game (T = 1, 2, 4): each computes a share of the 108 leaves
+//    and of the 36 (root, dice) scans and they swap results with DPP lane permutes inside
+//    the wavefront.  At 65 536 lanes a thread per game is ONE wave per SIMD; T lanes per
+//    game give T waves per SIMD, which is what hides LDS/global latency and doubles the
+//    VALU issue rate.  Everything not split is computed redundantly (identically) by the
+//    T lanes; only sub-lane 0 stores.
+#pragma once
+#include "ewn_fast.hpp"
+
+// ---- compile-time ring geometry (same order as build_fast_tables: ascending min(row,col), row-major inside a level)
+template <int S>
+struct RingGeo {
+    int ring_of_rm[S * S];   // canonical row-major cell -> ring index
+    int rm_of_ring[S * S];
+    constexpr RingGeo() : ring_of_rm(), rm_of_ring()
+    {
+        int n = 0;
+        for (int t = 0; t < S; t++)
+            for (int i = 0; i < S; i++)
+                for (int j = 0; j < S; j++)
+                    if ((i < j ? i : j) == t) { ring_of_rm[i * S + j] = n; rm_of_ring[n] = i * S + j; n++; }
+    }
+};
+
+// Quad-permute DPP (a VALU operand modifier: no LDS round trip).  The T lanes of a game are T consecutive
+// lanes inside one quad (T <= 4), so "lane j of my group" is a quad_perm broadcast.
+template <int CTRL> EWN_DEV u32 dpp_u32(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }
+template <int CTRL> EWN_DEV double dpp_f64(double v)
+{
+    const u64 b = (u64)__double_as_longlong(v);
+    const u32 lo = dpp_u32<CTRL>((u32)b), hi = dpp_u32<CTRL>((u32)(b >> 32));
+    return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+}
+// broadcast from lane J of a group of T lanes
+template <int T, int J> struct Bcast {
+    // T == 4: quad_perm [J,J,J,J]; T == 2: pairs (0,1) and (2,3): [J,J,2+J,2+J]
+    static constexpr int CTRL = T == 4 ? (J | (J << 2) | (J << 4) | (J << 6)) : (J | (J << 2) | ((2 + J) << 4) | ((2 + J) << 6));
+};
+// xor-1 / xor-2 lane swaps inside a quad
+#define DPP_XOR1 0xB1 /* quad_perm [1,0,3,2] */
+#define DPP_XOR2 0x4E /* quad_perm [2,3,0,1] */
+
+// Packed 6-bit fields
+EWN_DEV int pk_get(u64 w, int k) { return (int)((w >> (6 * k)) & 63ull); }
+EWN_DEV u64 pk_set(u64 w, int k, int c) { return (w & ~(63ull << (6 * k))) | ((u64)c << (6 * k)); }
+
+template <int S>
+struct RState {                 // one game, canonical ring space
+    typename MaskOf<S>::type P, N; // P: canonical TOP_LEFT (the opponent), N: canonical BOTTOM_RIGHT (the agent)
+    u64 posP, posN;             // ring index of cube k at bits [6k, 6k+6)
+    u32 aliveP, aliveN;
+};
+
+template <int S>
+EWN_DEV void rs_kill(RState<S> &s, int side_is_P, int q)
+{
+    typedef typename MaskOf<S>::type M;
+    const M one = 1;
+    u32 a = side_is_P ? s.aliveP : s.aliveN;
+    const u64 pos = side_is_P ? s.posP : s.posN;
+    #pragma unroll
+    for (int k = 0; k < 6; k++)
+        if (((a >> k) & 1u) && pk_get(pos, k) == q) a &= ~(1u << k);
+    if (side_is_P) { s.aliveP = a; s.P &= ~(one << q); } else { s.aliveN = a; s.N &= ~(one << q); }
+}
+
+// move cube k of one side to ring cell q (capture whatever is there, own cube included: envs/ewn.py:252-261)
+template <int S>
+EWN_DEV void rs_move(RState<S> &s, bool mover_is_P, int k, int q)
+{
+    typedef typename MaskOf<S>::type M;
+    const M one = 1, bq = one << q;
+    if (mover_is_P) {
+        if (s.N & bq) rs_kill<S>(s, 0, q); else if (s.P & bq) rs_kill<S>(s, 1, q);
+        s.P = (s.P & ~(one << pk_get(s.posP, k))) | bq;
+        s.posP = pk_set(s.posP, k, q);
+    } else {
+        if (s.P & bq) rs_kill<S>(s, 1, q); else if (s.N & bq) rs_kill<S>(s, 0, q);
+        s.N = (s.N & ~(one << pk_get(s.posN, k))) | bq;
+        s.posN = pk_set(s.posN, k, q);
+    }
+}
+
+// Depth-3 hybrid search in ring space, shared by T lanes (sub = my index in the group).
+// Every lane of the group returns the same (value, action).
+template <int S, int T>
+__device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S> &c, int dice, int sub, int &bflag, int &bdir)
+{
+    typedef typename MaskOf<S>::type M;
+    constexpr int IXN = FastTab<S>::IXN;
+    constexpr int KPT = 6 / T + (6 % T ? 1 : 0); // replier cubes / dice values per lane: k = sub + T*i
+    const M one = 1;
+
+    // my share of the replier's (cube, dir) moves; they never change during the search
+    M rset[KPT][3], rclr[KPT];
+    int rnk[KPT];
+    u32 legal = 0, hits_origin = 0, mine_alive = 0;
+    #pragma unroll
+    for (int i = 0; i < KPT; i++) {
+        const int k = sub + T * i;          // may be >= 6 for the last slot when 6 % T != 0: treated as a dead cube
+        const bool real = k < 6;
+        rnk[i] = pk_get(c.posN, real ? k : 0);
+        rclr[i] = ~(one << rnk[i]);
+        mine_alive |= ((real && ((c.aliveN >> k) & 1u)) ? 1u : 0u) << i;
+        #pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const int dn = Tb->nbn[d][rnk[i]];
+            const bool ok = dn != 255;
+            rset[i][d] = ok ? (one << dn) : (M)0;
+            legal |= (ok ? 1u : 0u) << (i * 3 + d);
+            hits_origin |= ((ok && dn == Tb->ri_origin) ? 1u : 0u) << (i * 3 + d);
+        }
+    }
+
+    // root slots: <= 2 cubes x 3 dirs in the reference's list order (envs/ewn.py:338-375)
+    const CubeSel cs = select_cubes(c.aliveP, dice);
+    const bool have0 = cs.exact || cs.has_up, have1 = !cs.exact && cs.has_down;
+    const int flag0 = cs.exact ? 0 : 1;
+    const int rp0 = pk_get(c.posP, have0 ? (cs.exact ? cs.k_exact : cs.k_up) : 0), rp1 = pk_get(c.posP, have1 ? cs.k_down : 0);
+
+    double best = -__builtin_inf(); // alpha = max(alpha, best_val): the running best (root beta stays +inf)
+    bflag = 0; bdir = 0;
+
+    // a real loop, not unrolled: the body is ~450 instructions and six copies of it (plus the rest of the
+    // kernel) do not fit the instruction cache shared by two CUs
+    #pragma unroll 1
+    for (int r = 0; r < 6; r++) {
+        const int slot = r >= 3 ? 1 : 0, dir = r - 3 * slot;
+        const int rp = slot == 0 ? rp0 : rp1;
+        const int dest = Tb->nbp[dir][rp];
+        const bool valid = (slot == 0 ? have0 : have1) && dest != 255;
+        const M bd = valid ? (one << dest) : (M)0;
+        const M P1 = (c.P & ~(one << rp)) | bd; // own capture: the bit is already set, the count drops by itself
+        const M N1 = c.N & ~bd;
+        const bool term = dest == FastTab<S>::CELLS - 1 || N1 == 0; // win(B1): value 10
+
+        // my leaves -> packed prefix minima of ranks per cube
+        u32 tr[6];
+        #pragma unroll
+        for (int i = 0; i < KPT; i++) {
+            const bool alive1 = ((mine_alive >> i) & 1u) && rnk[i] != dest;
+            const M Nk = N1 & rclr[i];
+            u32 a[3];
+            #pragma unroll
+            for (int d = 0; d < 3; d++) {
+                const M N2 = Nk | rset[i][d];
+                const M P2 = P1 & ~rset[i][d];
+                const int ix = Tb->lutx[clz_m(P2)] + popc_m(P2) * IXN;
+                const int iy = Tb->luty[clz_m(N2)] + popc_m(N2);
+                u32 rk = Tb->rank[ix + iy];
+                rk = (P2 == 0 || ((hits_origin >> (i * 3 + d)) & 1u)) ? 0u : rk;   // -10: envs/minimax_ewn.py:45-47
+                a[d] = (alive1 && ((legal >> (i * 3 + d)) & 1u)) ? rk : 1023u;
+            }
+            const u32 p1 = min(a[0], a[1]), p2 = min(p1, a[2]);
+            const u32 mine = a[0] | (p1 << 10) | (p2 << 20);
+            // publish to the group: after this every lane holds tr[k] for all six cubes (cube k = j + T*i lives in lane j)
+            if constexpr (T == 1) tr[i] = mine;
+            else if constexpr (T == 2) { tr[2 * i] = dpp_u32<Bcast<2, 0>::CTRL>(mine); tr[2 * i + 1] = dpp_u32<Bcast<2, 1>::CTRL>(mine); }
+            else {
+                if (i == 0) { tr[0] = dpp_u32<Bcast<4, 0>::CTRL>(mine); tr[1] = dpp_u32<Bcast<4, 1>::CTRL>(mine);
+                              tr[2] = dpp_u32<Bcast<4, 2>::CTRL>(mine); tr[3] = dpp_u32<Bcast<4, 3>::CTRL>(mine); }
+                else { tr[4] = dpp_u32<Bcast<4, 0>::CTRL>(mine); tr[5] = dpp_u32<Bcast<4, 1>::CTRL>(mine); }
+            }
+        }
+        // which cubes a dice value selects (find_near_cube): carry the nearest alive cube's data along
+        u32 upT[6], downT[6];
+        {
+            u32 cur = FAST_NONE;
+            #pragma unroll
+            for (int d = 5; d >= 0; d--) { upT[d] = cur; cur = tr[d] != FAST_NONE ? tr[d] : cur; }
+            cur = FAST_NONE;
+            #pragma unroll
+            for (int d = 0; d < 6; d++) { downT[d] = cur; cur = tr[d] != FAST_NONE ? tr[d] : cur; }
+        }
+        // the (first, second) reply cubes of every dice value (get_legal_actions order: larger neighbour first)
+        u32 Fd[6], Gd[6];
+        #pragma unroll
+        for (int d = 0; d < 6; d++) {
+            const bool exact = tr[d] != FAST_NONE;
+            const bool up = upT[d] != FAST_NONE;
+            Fd[d] = exact ? tr[d] : (up ? upT[d] : downT[d]);
+            Gd[d] = (!exact && up) ? downT[d] : FAST_NONE;
+        }
+        // my share of the six chance branches: dice index d = sub + T*i
+        double q[6];
+        #pragma unroll
+        for (int i = 0; i < KPT; i++) {
+            u32 F = FAST_NONE, G = FAST_NONE;
+            #pragma unroll
+            for (int j = 0; j < T; j++)
+                if (T * i + j < 6) { F = sub == j ? Fd[T * i + j] : F; G = sub == j ? Gd[T * i + j] : G; }
+            const int x0 = (int)(F & 1023u), x1 = (int)((F >> 10) & 1023u), x2 = (int)(F >> 20);
+            const int y0 = min(x2, (int)(G & 1023u)), y1 = min(x2, (int)((G >> 10) & 1023u)), y2 = min(x2, (int)(G >> 20));
+            // `worst <= alpha` (minimax.py:59-61) vs alpha = best so far; val[1023] = +inf marks "no such reply"
+            int w = y2;
+            w = max(w, Tb->val[x0] <= best ? x0 : 0);
+            w = max(w, Tb->val[x1] <= best ? x1 : 0);
+            w = max(w, Tb->val[x2] <= best ? x2 : 0);
+            w = max(w, Tb->val[y0] <= best ? y0 : 0);
+            w = max(w, Tb->val[y1] <= best ? y1 : 0);
+            const double mine = Tb->val6[min(w, 1023)];
+            if constexpr (T == 1) q[i] = mine;
+            else if constexpr (T == 2) { q[2 * i] = dpp_f64<Bcast<2, 0>::CTRL>(mine); q[2 * i + 1] = dpp_f64<Bcast<2, 1>::CTRL>(mine); }
+            else {
+                if (i == 0) { q[0] = dpp_f64<Bcast<4, 0>::CTRL>(mine); q[1] = dpp_f64<Bcast<4, 1>::CTRL>(mine);
+                              q[2] = dpp_f64<Bcast<4, 2>::CTRL>(mine); q[3] = dpp_f64<Bcast<4, 3>::CTRL>(mine); }
+                else { q[4] = dpp_f64<Bcast<4, 0>::CTRL>(mine); q[5] = dpp_f64<Bcast<4, 1>::CTRL>(mine); }
+            }
+        }
+        double v = 0.0;
+        #pragma unroll
+        for (int d = 0; d < 6; d++) v = v + q[d]; // expected_val += val / 6 in dice order, minimax.py:72
+        v = term ? 10.0 : v;
+        if (valid && v > best) { best = v; bflag = slot == 0 ? flag0 : 0; bdir = dir; }
+    }
+    return best;
+}
+
+// ---------------------------------------------------------------- the fused step kernel
+
+struct D3Cfg {
+    int N, rng_kind, autoreset;
+    u32 seed_stride, W;
+    double reward;
+    u64 key;
+};
+
+struct D3Buf {
+    int8_t *board; int8_t *dice; uint8_t *done; u32 *rng; const void *tables; const int8_t *actions;
+    double *reward; uint8_t *terminated; uint8_t *truncated; uint8_t *info; int8_t *tboard; int8_t *tdice;
+};
+
+#define D3_BS 256
+
+// real board bytes -> canonical ring state.  Real value v > 0 is the agent's cube v (canonical BOTTOM_RIGHT side),
+// v < 0 the opponent's cube |v| (canonical TOP_LEFT side); real cell c sits at canonical cell S*S-1-c, whose ring
+// index is a compile-time constant.  The T lanes of a game scan interleaved cells and OR their partial states.
+template <int S, int T>
+EWN_DEV void d3_decode(const int8_t *b, int sub, RState<S> &s)
+{
+    typedef typename MaskOf<S>::type M;
+    constexpr RingGeo<S> G{};
+    M P = 0, N = 0;
+    u64 posP = 0, posN = 0;
+    u32 aP = 0, aN = 0;
+    #pragma unroll
+    for (int c0 = 0; c0 < S * S; c0 += T) {
+        #pragma unroll
+        for (int j = 0; j < T; j++) {
+            const int c = c0 + j;
+            if (c >= S * S) continue;
+            const bool mine = T == 1 || sub == j;
+            const int v = mine ? (int)b[c] : 0;
+            const int ring = G.ring_of_rm[S * S - 1 - c];
+            const u32 mpos = (u32)((0 - v) >> 31), mneg = (u32)(v >> 31);   // all ones where v > 0 / v < 0
+            const int k1 = max(v, 0 - v);                                       // |v|, 0 for an empty cell
+            const u32 abit = (1u << ((k1 - 1) & 31)) & 63u;                     // empty cell: bit 31 -> masked off
+            const u64 pbits = (u64)ring << ((6 * k1 - 6) & 63);
+            N |= (M)((M)1 << ring) & (M)(M)(0 - (M)(mpos & 1u));
+            P |= (M)((M)1 << ring) & (M)(M)(0 - (M)(mneg & 1u));
+            aN |= abit & mpos; aP |= abit & mneg;
+            posN |= pbits & (0ull - (u64)(mpos & 1u)); posP |= pbits & (0ull - (u64)(mneg & 1u));
+        }
+    }
+    if constexpr (T >= 2) {
+        #define D3_OR32(x, ctrl) x |= dpp_u32<ctrl>(x)
+        #define D3_OR64(x, ctrl) x |= ((u64)dpp_u32<ctrl>((u32)(x >> 32)) << 32) | dpp_u32<ctrl>((u32)x)
+        u64 P64 = (u64)P, N64 = (u64)N;
+        D3_OR64(P64, DPP_XOR1); D3_OR64(N64, DPP_XOR1); D3_OR64(posP, DPP_XOR1); D3_OR64(posN, DPP_XOR1); D3_OR32(aP, DPP_XOR1); D3_OR32(aN, DPP_XOR1);
+        if constexpr (T == 4) {
+            D3_OR64(P64, DPP_XOR2); D3_OR64(N64, DPP_XOR2); D3_OR64(posP, DPP_XOR2); D3_OR64(posN, DPP_XOR2); D3_OR32(aP, DPP_XOR2); D3_OR32(aN, DPP_XOR2);
+        }
+        P = (M)P64; N = (M)N64;
+        #undef D3_OR32
+        #undef D3_OR64
+    }
+    s.P = P; s.N = N; s.posP = posP; s.posN = posN; s.aliveP = aP; s.aliveN = aN;
+}
+
+// canonical ring state -> real board bytes (LDS), the T lanes writing interleaved shares
+template <int S, int T>
+EWN_DEV void d3_encode(const FastTab<S> *Tb, const RState<S> &s, int sub, int8_t *b)
+{
+    #pragma unroll
+    for (int c = 0; c < S * S; c++) if (T == 1 || c % T == sub) b[c] = 0;
+    __builtin_amdgcn_wave_barrier(); // the zeroing of every lane of the group is issued before any cube byte
+    #pragma unroll
+    for (int k = 0; k < 6; k++) {
+        if (T == 1 || (2 * k) % T == sub) if ((s.aliveN >> k) & 1u) b[Tb->real_of_ring[pk_get(s.posN, k)]] = (int8_t)(k + 1);
+        if (T == 1 || (2 * k + 1) % T == sub) if ((s.aliveP >> k) & 1u) b[Tb->real_of_ring[pk_get(s.posP, k)]] = (int8_t)(-(k + 1));
+    }
+}
+
+template <int S>
+EWN_DEV void d3_init_state(const FastTab<S> *Tb, RState<S> &s)
+{
+    typedef typename MaskOf<S>::type M;
+    s.P = (M)Tb->init_P; s.N = (M)Tb->init_N; s.posP = Tb->init_posP; s.posN = Tb->init_posN; s.aliveP = s.aliveN = 63u;
+}
+
+// reset(seed) + setup_game (envs/ewn.py:488-494, 94-108)
+template <int S>
+__device__ void d3_reset(const FastTab<S> *Tb, const D3Cfg &c, u32 seed, u32 *win, RState<S> &s, int &dice, LaneRng &r)
+{
+    // all T lanes of the group fill the window with identical values (each lane only ever reads back its own stores)
+    if (c.rng_kind == 0) mt_fill_window(seed, (int)c.W, win);
+    r.load(c.rng_kind, make_uint4(seed, 0u, seed + c.seed_stride, 0u), win, c.W, c.key);
+    d3_init_state<S>(Tb, s);
+    dice = r.randint(1, 7);
+}
+
+// EinsteinWuerfeltNichtEnv.step (envs/ewn.py:436-486), minimax(depth 3, hybrid) opponent, cube_layer 3.
+// T lanes per game; lanes of a group run identical code on identical data except inside d3_search.
+template <int S, int T>
+__global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
+{
+    constexpr int CELLS = S * S, GPB = D3_BS / T; // games per block
+    extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+    int8_t *lds_t = lds + GPB * CELLS;
+    int8_t *tb = lds + ((2 * GPB * CELLS + 15) & ~15);
+    tables_to_lds<FAST_TAB_BYTES(S)>(tb, (const int8_t *)B.tables); // LDS-DMA, waited for at the barrier
+    const FastTab<S> *Tb = (const FastTab<S> *)tb;
+
+    const int g0 = blockIdx.x * GPB, ng = min(GPB, c.N - g0);
+    const int gl = threadIdx.x / T, sub = threadIdx.x % T, game = g0 + gl;
+    const bool live = game < c.N, writer = sub == 0;
+
+    uint4 hdr = make_uint4(0u, 0u, 0u, 0u);
+    int dice = 1, aflag = 0, adir = 0;
+    bool frozen = false;
+    if (live) {
+        hdr = *rng_hdr_ptr(B.rng, game);
+        dice = B.dice[game];
+        frozen = B.done[game] != 0;
+        const uint16_t a2 = ((const uint16_t *)B.actions)[game];
+        aflag = (int8_t)(a2 & 0xff); adir = (int8_t)(a2 >> 8);
+    }
+    block_copy_in(lds, B.board + (size_t)g0 * CELLS, ng * CELLS);
+    __syncthreads();
+
+    int8_t *mine = lds + gl * CELLS, *mine_t = lds_t + gl * CELLS;
+    double reward = 0.0;
+    int term = 0, trunc = 0, info = EWN_INFO_NONE;
+    RState<S> s;
+    u32 *win = rng_win_ptr(B.rng, c.N, c.W, live ? game : 0);
+    LaneRng r; r.load(c.rng_kind, hdr, win, c.W, c.key);
+    d3_decode<S, T>(live ? mine : lds, sub, s); // every lane takes part (DPP combine); non-live lanes read game 0 of the block
+    const bool active = live && !frozen;
+    bool reply = false;
+    if (frozen) term = 1; // no reference counterpart: a finished, un-reset game stays put
+    if (active) {
+        // agent half, envs/ewn.py:438-458 (the agent is the canonical BOTTOM_RIGHT side)
+        const CubeSel cs = select_cubes(s.aliveN, dice);
+        const int k = cube_to_move(cs, aflag == 1);
+        const int q = (k >= 0 && adir >= 0 && adir <= 2) ? Tb->nbn[adir][pk_get(s.posN, k)] : 255;
+        if (q == 255) { reward = -c.reward; term = 1; trunc = 1; info = EWN_INFO_INVALID_PLAYER; }
+        else {
+            rs_move<S>(s, false, k, q);
+            if (q == Tb->ri_origin || s.P == 0) { reward = c.reward; term = 1; info = EWN_INFO_WON; }
+            else { dice = r.randint(1, 7); reply = true; }
+        }
+    }
+    // the opponent's search: run by every lane (lanes without a pending reply compute on a harmless state),
+    // so the DPP exchanges inside always see their partners
+    int oflag = 0, odir = 0;
+    d3_search<S, T>(Tb, s, dice, sub, oflag, odir);
+    if (reply) {
+        // opponent half, envs/ewn.py:464-486
+        const CubeSel cs = select_cubes(s.aliveP, dice);
+        const int k = cube_to_move(cs, oflag == 1);
+        const int q = Tb->nbp[odir][pk_get(s.posP, k)];
+        rs_move<S>(s, true, k, q);
+        if (q == CELLS - 1 || s.N == 0) { reward = -c.reward; term = 1; info = EWN_INFO_LOST; }
+        else dice = r.randint(1, 7);
+    }
+    if (live && B.tboard) { if (active) d3_encode<S, T>(Tb, s, sub, mine_t); else if (writer) for (int i = 0; i < CELLS; i++) mine_t[i] = mine[i]; }
+    if (live && writer && B.tdice) B.tdice[game] = (int8_t)dice;
+    if (active) {
+        if (term) {
+            if (c.autoreset) d3_reset<S>(Tb, c, r.next_seed, win, s, dice, r);
+            else if (writer) B.done[game] = 1;
+        }
+        d3_encode<S, T>(Tb, s, sub, mine);
+        if (writer) {
+            *rng_hdr_ptr(B.rng, game) = r.header();
+            B.dice[game] = (int8_t)dice;
+        }
+    }
+    if (live && writer) {
+        B.reward[game] = reward; B.terminated[game] = (uint8_t)term;
+        B.truncated[game] = (uint8_t)trunc; B.info[game] = (uint8_t)info;
+    }
+    __syncthreads();
+    block_copy_out(B.board + (size_t)g0 * CELLS, lds, ng * CELLS);
+    if (B.tboard) block_copy_out(B.tboard + (size_t)g0 * CELLS, lds_t, ng * CELLS);
+}
