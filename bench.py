@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly from Python instead of replaying a hipGraph")
+    ap.add_argument("--graph-steps", type=int, default=50, help="steps captured per graph")
     return ap.parse_args()
 
 
@@ -87,51 +89,69 @@ def main():
     env = ea.VecEWN(N, board_size=args.board_size, cube_layer=args.cube_layer, opponent_policy=args.opponent,
                     max_depth=args.max_depth, rng=args.rng, autoreset=True, lane_offset=lo, seed_stride=N * world,
                     philox_key=2024)
-    seeds = (torch.arange(lo, hi, dtype=torch.int64) + 9487).to(torch.int32)  # reference default seed 9487 + global lane id
-    env.reset(seeds=seeds.cuda())
+    from ewn_gym_amd.sharding import lane_seeds
+    env.reset(seeds=lane_seeds(lo, hi).cuda())  # reference default seed 9487 + global lane id
     actions = torch.zeros((N, 2), dtype=torch.int8, device="cuda")
 
-    def one_step(t):
-        env.sample_legal_actions(t, out=actions)
-        env.step(actions)
+    counter = torch.zeros((), dtype=torch.int32, device="cuda")  # device-side step index: lets the captured graph advance
 
-    for t in range(args.warmup):
-        one_step(t)
-    ev = None
-    if not args.no_kernel_timing:
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    term_count = torch.zeros((), dtype=torch.int64, device="cuda")
+    def one_step():
+        env.sample_legal_actions(0, out=actions, step_tensor=counter)   # the stand-in agent (RandomAgent as a device policy)
+        env.step(actions)                                               # the hot path
+        counter.add_(1)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(args.warmup):
+        one_step()
+    # The per-step launch sequence is captured once in a hipGraph (same kernels, same order, same stream semantics) so the
+    # timed region measures the GPU, not Python's ctypes launch overhead (~7 us/step on this host).
+    graph = None
+    if not args.no_graph:
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(args.graph_steps):
+                one_step()
+    n_rep = args.steps // args.graph_steps if graph is not None else 0
+    n_tail = args.steps - n_rep * (args.graph_steps if graph is not None else 0)
+
     barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        t = args.warmup + k
-        env.sample_legal_actions(t, out=actions)
-        if ev is not None:
-            ev[k][0].record()
-        env.step(actions)
-        if ev is not None:
-            ev[k][1].record()
+    for _ in range(n_rep):
+        graph.replay()
+    for _ in range(n_tail):
+        one_step()
     barrier()
     dt = time.perf_counter() - t0
-    term_count += env.terminated.sum()
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+
+    # Dominant-kernel duration: the same K steps again, launched eagerly with a HIP event pair around every ewn_step on the
+    # launch stream (a graph replay cannot be bracketed per kernel).  rocprofv3 --kernel-trace of this command must agree.
+    kms = None
+    if not args.no_kernel_timing:
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for k in range(args.steps):
+            env.sample_legal_actions(0, out=actions, step_tensor=counter)
+            ev[k][0].record()
+            env.step(actions)
+            ev[k][1].record()
+            counter.add_(1)
+        torch.cuda.synchronize()
+        kms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
 
     if rank == 0:
         total_steps = N * world * args.steps
         value = total_steps / dt
         bytes_per = ALGO_BYTES_PER_LANE_STEP.get(args.board_size, 2 * args.board_size ** 2 + 10)
         roof = None
-        if ev is not None:
-            kms = sum(a.elapsed_time(b) for a, b in ev) / args.steps  # ms per ewn_step launch (HIP events on the launch stream)
+        if kms is not None:
             achieved = N * bytes_per / (kms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -159,6 +179,7 @@ def main():
                                       " depth %d (hybrid heuristic)" % args.max_depth if args.opponent == "minimax" else "", args.rng),
                        "lanes_per_gpu": N, "board_size": args.board_size, "cube_layer": args.cube_layer,
                        "opponent": args.opponent, "max_depth": args.max_depth, "rng": args.rng,
+                       "launch": "hipGraph replay (%d steps per graph)" % args.graph_steps if graph is not None else "eager",
                        "parallelism": "lanes sharded across %d GPU(s), no data-path collective" % world},
             "roofline": roof, "cpu_baseline": cpub,
         }

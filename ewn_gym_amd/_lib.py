@@ -80,7 +80,7 @@ def load():
         "ewn_legal_actions": (i32, [i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
         "ewn_evaluate": (i32, [i32, i32, i32, vp, i32, vp, vp]),
         "ewn_predict_minimax": (i32, [i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp]),
-        "ewn_predict_random": (i32, [i32, i32, i32, vp, vp, u64, u32, i32, vp, vp]),
+        "ewn_predict_random": (i32, [i32, i32, i32, vp, vp, u64, u32, vp, i32, vp, vp]),
         "ewn_predict_mcts": (i32, [i32, i32, i32, vp, vp, i32, i32, u64, vp, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():

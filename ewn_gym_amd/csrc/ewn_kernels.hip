@@ -386,8 +386,9 @@ __global__ __launch_bounds__(BS) void k_predict_minimax_fast(Geom g, int M, cons
 
 template <int NW>
 __global__ __launch_bounds__(BS) void k_predict_random(Geom g, int M, const int8_t *boards, const int8_t *dice, u64 key, u32 step,
-                                                       int lane_offset, int8_t *actions)
+                                                       const u32 *step_dev, int lane_offset, int8_t *actions)
 {
+    if (step_dev) step += *step_dev;
     const int m = blockIdx.x * BS + threadIdx.x;
     if (m >= M) return;
     GState<NW> s;
@@ -848,7 +849,7 @@ int ewn_predict_minimax(int board_size, int cube_layer, int M, const int8_t *boa
 }
 
 int ewn_predict_random(int board_size, int cube_layer, int M, const int8_t *boards, const int8_t *dice, uint64_t key,
-                       uint32_t step, int32_t lane_offset, int8_t *actions, void *stream)
+                       uint32_t step, const uint32_t *step_dev, int32_t lane_offset, int8_t *actions, void *stream)
 {
     Geom g;
     int rc = query_geom(board_size, cube_layer, M, boards, g);
@@ -856,8 +857,8 @@ int ewn_predict_random(int board_size, int cube_layer, int M, const int8_t *boar
     if (M == 0) return EWN_OK;
     if (!dice || !actions) return EWN_ENULL;
     hipStream_t s = (hipStream_t)stream;
-    BY_NW(g, (k_predict_random<1><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, key, step, lane_offset, actions)),
-          (k_predict_random<2><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, key, step, lane_offset, actions)));
+    BY_NW(g, (k_predict_random<1><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, key, step, step_dev, lane_offset, actions)),
+          (k_predict_random<2><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, key, step, step_dev, lane_offset, actions)));
     return launch_status();
 }
 

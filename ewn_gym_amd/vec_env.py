@@ -114,11 +114,13 @@ class VecEWN:
         return self.board, self.dice, self.reward, self.terminated, self.truncated, self.info
 
     # -- RandomAgent as a stateless device policy (classical_policies/random_policy.py:11-15)
-    def sample_legal_actions(self, step, out=None):
+    def sample_legal_actions(self, step, out=None, step_tensor=None):
+        """step_tensor: optional int32 device scalar added to `step` on the device (lets a captured graph advance)"""
         out = self._actions if out is None else out
         check(self.lib.ewn_predict_random(self.S, self.L, self.N, _ptr(self.board), _ptr(self.dice),
                                           C.c_uint64(self.cfg.philox_key), C.c_uint32(int(step) & 0xFFFFFFFF),
-                                          int(self.cfg.lane_offset), _ptr(out), _stream()), "ewn_predict_random")
+                                          _ptr(step_tensor), int(self.cfg.lane_offset), _ptr(out), _stream()),
+              "ewn_predict_random")
         return out
 
     def set_obs(self, boards, dice):
@@ -194,8 +196,8 @@ def predict_random(boards, dice, key=0, step=0, lane_offset=0, cube_layer=3):
     lib = _lib.load()
     b, d, M, S, dev = _prep(boards, dice)
     acts = torch.zeros((M, 2), dtype=torch.int8, device=dev)
-    check(lib.ewn_predict_random(S, cube_layer, M, _ptr(b), _ptr(d), C.c_uint64(key), C.c_uint32(step), int(lane_offset),
-                                 _ptr(acts), _stream()), "ewn_predict_random")
+    check(lib.ewn_predict_random(S, cube_layer, M, _ptr(b), _ptr(d), C.c_uint64(key), C.c_uint32(step), None,
+                                 int(lane_offset), _ptr(acts), _stream()), "ewn_predict_random")
     return acts
 
 

@@ -171,9 +171,10 @@ int ewn_predict_minimax(int board_size, int cube_layer, int M, const int8_t *boa
                         int heuristic, int8_t *actions, double *values, const void *tables, void *stream);
 
 /* RandomAgent.predict (classical_policies/random_policy.py:11-15) as a stateless policy:
- * uniform legal action from Philox ctr={step, lane_offset+i, 'AGNT', 0}, key. */
+ * uniform legal action from Philox ctr={step + (step_dev ? *step_dev : 0), lane_offset+i, 'AGNT', 0}, key.
+ * step_dev (device pointer, may be NULL) lets a captured hipGraph advance the stream between replays. */
 int ewn_predict_random(int board_size, int cube_layer, int M, const int8_t *boards, const int8_t *dice, uint64_t key,
-                       uint32_t step, int32_t lane_offset, int8_t *actions, void *stream);
+                       uint32_t step, const uint32_t *step_dev, int32_t lane_offset, int8_t *actions, void *stream);
 
 /* MctsAgent.predict (classical_policies/mcts.py:102-106, flat Monte-Carlo :47-69, rollouts :21-45).
  * wins [M][6] int32 is REQUIRED scratch/output (win count per root move, -1 = no such move).
