@@ -1,0 +1,77 @@
+"""Command-line counterpart of the reference's train.py (argument names follow train.py:162-259
+where they apply): A2C on VecEWN lanes instead of SubprocVecEnv workers, per-epoch evaluation
+against minimax on the un-shaped env (train.py:66-117), best-model checkpointing.
+
+  python -m ewn_gym_amd.train_a2c --num_envs 4096 --epoch_num 10 --timesteps_per_epoch 200000
+  python -m torch.distributed.run --nproc-per-node 8 -m ewn_gym_amd.train_a2c ...   (one process per GPU, RCCL)
+"""
+import argparse
+import json
+import os
+
+import torch
+import torch.distributed as dist
+
+from .a2c import A2CTrainer
+from .sharding import all_reduce_counters, lane_range, lane_seeds
+from .tournament import evaluate
+from .vec_env import VecEWN
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--num_envs", "-ne", type=int, default=4096, help="lanes per GPU")
+    ap.add_argument("--n_steps", "-n", type=int, default=5)
+    ap.add_argument("--learning_rate", "-lr", type=float, default=3e-4)
+    ap.add_argument("--epoch_num", "-e", type=int, default=10)
+    ap.add_argument("--timesteps_per_epoch", "-t", type=int, default=200000)
+    ap.add_argument("--eval_episode_num", "-ee", type=int, default=256)
+    ap.add_argument("--eval_max_depth", type=int, default=5)
+    ap.add_argument("--board_size", type=int, default=5)
+    ap.add_argument("--cube_layer", type=int, default=3)
+    ap.add_argument("--opponent_policy", "-op", default="random")
+    ap.add_argument("--max_depth", type=int, default=3)
+    ap.add_argument("--goal_reward", type=float, default=10.0)
+    ap.add_argument("--illegal_move_reward", type=float, default=-1.0)
+    ap.add_argument("--illegal_move_tolerance", type=int, default=10)
+    ap.add_argument("--reference_quirks", action="store_true",
+                    help="reproduce MinimaxEnv's ctor-argument dropping: RandomAgent opponent, reward 1.0 (SURVEY App. D1)")
+    ap.add_argument("--seed", type=int, default=9487)
+    ap.add_argument("--save_dir", default="models")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl")
+    lo, hi = lane_range(a.num_envs * world, world, rank)
+    opp, reward = (("random", 1.0) if a.reference_quirks else (a.opponent_policy, a.goal_reward))
+    env = VecEWN(a.num_envs, board_size=a.board_size, cube_layer=a.cube_layer, opponent_policy=opp, max_depth=a.max_depth,
+                 rng="philox", shaped=True, reward=reward, illegal_move_reward=a.illegal_move_reward,
+                 illegal_move_tolerance=a.illegal_move_tolerance, autoreset=True, lane_offset=lo,
+                 seed_stride=a.num_envs * world, philox_key=a.seed, shaped_refresh_on_reset=not a.reference_quirks)
+    env.reset(seeds=lane_seeds(lo, hi, a.seed).cuda())
+    trainer = A2CTrainer(env, n_steps=a.n_steps, learning_rate=a.learning_rate, seed=a.seed)
+    best = -1.0
+    for epoch in range(a.epoch_num):
+        stats = trainer.learn(a.timesteps_per_epoch // world)
+        # train.py:73-81: evaluate on the UN-shaped env against minimax(depth 5), seeds 0..n-1, deterministic actions
+        n_eval = a.eval_episode_num // world
+        r = evaluate(trainer.policy_fn(True), {"kind": "minimax", "max_depth": a.eval_max_depth}, num=n_eval,
+                     board_size=a.board_size, cube_layer=a.cube_layer, rng="mt19937", seed_offset=rank * n_eval)
+        c = all_reduce_counters(torch.tensor([r["wins"], r["episodes"]], dtype=torch.int64, device="cuda"))
+        win_rate = c[0].item() / max(1, c[1].item())
+        if rank == 0:
+            print(json.dumps({"epoch": epoch, "timesteps": trainer.num_timesteps * world, "win_rate": win_rate, **stats}), flush=True)
+            if win_rate > best:          # train.py:109-112
+                best = win_rate
+                os.makedirs(a.save_dir, exist_ok=True)
+                trainer.save(os.path.join(a.save_dir, "best.pt"))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -271,6 +271,26 @@ def main():
         g8["raw"].append({"seed": seed, "randint": seq, "u32": raw})
     dump("g8_rng.json", g8)
 
+    # ---- G10: evaluation() of eval_minimax.py:16-50 with the deterministic minimax agent -------------------------
+    g10 = []
+    for (adepth, opp, odepth), nseed in (((3, ClassicalPolicy.random, None), 64), ((2, ClassicalPolicy.minimax, 3), 32),
+                                         ((3, ClassicalPolicy.minimax, 3), 32), ((1, ClassicalPolicy.random, None), 64)):
+        kw = {} if odepth is None else {"max_depth": odepth}
+        env = envs.EinsteinWuerfeltNichtEnv(board_size=5, cube_layer=3, opponent_policy=opp, **kw)
+        model = cp.ExpectiMinimaxAgent(adepth, 3, 5)
+        scores, lengths = [], []
+        for seed in range(nseed):
+            obs, info = env.reset(seed=seed)
+            done, n, reward = False, 0, 0
+            while not done:
+                action, _ = model.predict(obs, deterministic=True)
+                obs, reward, done, _, info = env.step(action)
+                n += 1
+            scores.append(float(reward))
+            lengths.append(n)
+        g10.append({"agent_depth": adepth, "opp": str(opp), "opp_depth": odepth, "scores": scores, "lengths": lengths})
+    dump("g10_eval_loop.json", g10)
+
     # ---- G9: flat Monte-Carlo statistics ---------------------------------------------------
     import copy
     import random as pyrandom

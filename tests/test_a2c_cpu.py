@@ -1,0 +1,84 @@
+"""Trainer counterpart, CPU side: return computation, feature layout, and the one
+gradient all-reduce of the multi-GPU path exercised with two gloo ranks."""
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ewn_gym_amd.a2c import ActorCritic, all_reduce_gradients, n_step_returns
+
+
+def test_n_step_returns_match_a_plain_loop():
+    g = torch.Generator().manual_seed(0)
+    T, N, gamma = 7, 5, 0.9
+    r = torch.randn(T, N, generator=g)
+    v = torch.randn(T, N, generator=g)
+    d = (torch.rand(T, N, generator=g) < 0.3).float()
+    lv = torch.randn(N, generator=g)
+    adv, ret = n_step_returns(r, v, d, lv, gamma, 1.0)
+    for n in range(N):
+        for t in range(T):
+            G, disc = 0.0, 1.0
+            k = t
+            while True:
+                G += disc * r[k, n].item()
+                if d[k, n] == 1:
+                    break
+                disc *= gamma
+                k += 1
+                if k == T:
+                    G += disc * lv[n].item()
+                    break
+            assert abs(ret[t, n].item() - G) < 1e-5
+    assert torch.allclose(adv, ret - v)
+
+
+def test_features_and_parameter_budget():
+    m = ActorCritic(5, 6)
+    board = torch.zeros(3, 5, 5, dtype=torch.int8)
+    board[0, 0, 0] = 4
+    board[1, 4, 4] = -2
+    x = m.features(board, torch.tensor([1, 6, 3], dtype=torch.int8))
+    assert x.shape == (3, 25 + 7)
+    assert x[0, 0] == 4 and x[1, 24] == -2
+    assert x[:, 25:].argmax(1).tolist() == [0, 5, 2] and x[:, 25:].sum(1).tolist() == [1, 1, 1]
+    n = sum(p.numel() for p in m.parameters())
+    assert 12000 < n < 14000          # ~13 k fp32 = 52 KB: one all-reduce bucket
+    a, v = m.act(board, torch.tensor([1, 6, 3], dtype=torch.int8), deterministic=True)
+    assert a.shape == (3, 2) and a.dtype == torch.int8 and bool((a[:, 0] < 2).all()) and bool((a[:, 1] < 3).all())
+
+
+def _worker(rank, world, port, q):
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    torch.manual_seed(0)
+    m = ActorCritic(5, 6)
+    g = torch.Generator().manual_seed(100 + rank)
+    board = torch.randint(-6, 7, (16, 5, 5), generator=g).to(torch.int8)
+    dice = torch.randint(1, 7, (16,), generator=g).to(torch.int8)
+    acts = torch.stack([torch.randint(0, 2, (16,), generator=g), torch.randint(0, 3, (16,), generator=g)], 1)
+    logp, ent, val = m.evaluate_actions(board, dice, acts)
+    (logp.mean() + val.pow(2).mean()).backward()
+    local = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+    all_reduce_gradients(list(m.parameters()))
+    red = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+    q.put((rank, local, red))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_single_bucket_gradient_all_reduce_with_two_gloo_ranks():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict((r, (l, g)) for r, l, g in (q.get(timeout=120) for _ in range(2)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    mean = (res[0][0] + res[1][0]) / 2
+    assert torch.allclose(res[0][1], mean, atol=1e-7) and torch.allclose(res[1][1], mean, atol=1e-7)
