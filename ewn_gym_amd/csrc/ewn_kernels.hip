@@ -388,12 +388,15 @@ template <int NW>
 __global__ __launch_bounds__(BS) void k_predict_random(Geom g, int M, const int8_t *boards, const int8_t *dice, u64 key, u32 step,
                                                        const u32 *step_dev, int lane_offset, int8_t *actions)
 {
+    extern __shared__ __attribute__((aligned(16))) int8_t lds[];
     if (step_dev) step += *step_dev;
-    const int m = blockIdx.x * BS + threadIdx.x;
+    const int m0 = blockIdx.x * BS, nm = min(BS, M - m0), m = m0 + threadIdx.x;
+    block_copy_in(lds, boards + (size_t)m0 * g.cells, nm * g.cells); // coalesced 16-byte pieces instead of 25 byte loads per lane
+    const int d = m < M ? dice[m] : 1;
+    __syncthreads();
     if (m >= M) return;
     GState<NW> s;
-    decode_board<NW>(g, boards + (size_t)m * g.cells, s);
-    const int d = dice[m];
+    decode_board<NW>(g, lds + threadIdx.x * g.cells, s);
     int f = 0, dr = 0;
     if (s.aliveP != 0 && d >= 1 && d <= g.CN) {
         const int n = for_each_legal<0, NW>(g, s, d, [](int, int, int) { return true; });
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(BS) void k_predict_random(Geom g, int M, const int8
         int i = 0;
         for_each_legal<0, NW>(g, s, d, [&](int flag, int, int dir) { if (i == pick) { f = flag; dr = dir; } i++; return i <= pick; });
     }
-    actions[2 * m] = (int8_t)f; actions[2 * m + 1] = (int8_t)dr;
+    ((uint16_t *)actions)[m] = (uint16_t)((uint8_t)f | ((uint16_t)(uint8_t)dr << 8));
 }
 
 // ---------------------------------------------------------------- flat Monte-Carlo ("MCTS")
@@ -740,17 +743,18 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
     if (cfg->opponent_kind != EWN_OPP_MCTS) {
         const bool fast = st->tables && fast_tables_bytes(g.S, g.L) > 0 && cfg->opponent_kind == EWN_OPP_MINIMAX &&
                           cfg->max_depth == 3 && cfg->heuristic == EWN_H_HYBRID;
-        if (fast && !cfg->shaped && d3_threads_per_game(k.N) > 0) {
+        const bool lean_random = st->tables && fast_tables_bytes(g.S, g.L) > 0 && cfg->opponent_kind == EWN_OPP_RANDOM;
+        if ((fast || lean_random) && !cfg->shaped && d3_threads_per_game(k.N) > 0) {
             // the lean fused kernel: canonical ring space end to end, T lanes per game (ewn_step_d3.hpp)
-            const int T = d3_threads_per_game(k.N);
+            const int T = lean_random ? 1 : d3_threads_per_game(k.N);
             D3Cfg dc = { k.N, k.rng_kind, k.autoreset, k.seed_stride, k.W, k.reward, k.key };
             D3Buf db = { st->board, st->dice, st->done, st->rng, st->tables, actions, out->reward, out->terminated,
                          out->truncated, out->info, out->terminal_board, out->terminal_dice };
             const int gpb = D3_BS / T;
             const dim3 grid((unsigned)((k.N + gpb - 1) / gpb));
             const size_t l3 = (((size_t)2 * gpb * g.cells + 15) & ~(size_t)15);
-#define D3_LAUNCH(SS, TT) k_step_d3<SS, TT><<<grid, D3_BS, l3 + FAST_TAB_BYTES(SS), s>>>(dc, db)
-#define D3_BY_T(SS) do { if (T == 1) D3_LAUNCH(SS, 1); else if (T == 2) D3_LAUNCH(SS, 2); else D3_LAUNCH(SS, 4); } while (0)
+#define D3_LAUNCH(SS, TT, OO) k_step_d3<SS, TT, OO><<<grid, D3_BS, l3 + FAST_TAB_BYTES(SS), s>>>(dc, db)
+#define D3_BY_T(SS) do { if (lean_random) D3_LAUNCH(SS, 1, 1); else if (T == 1) D3_LAUNCH(SS, 1, 0); else if (T == 2) D3_LAUNCH(SS, 2, 0); else D3_LAUNCH(SS, 4, 0); } while (0)
             switch (g.S) {
             case 5: D3_BY_T(5); break;
             case 6: D3_BY_T(6); break;
@@ -857,8 +861,8 @@ int ewn_predict_random(int board_size, int cube_layer, int M, const int8_t *boar
     if (M == 0) return EWN_OK;
     if (!dice || !actions) return EWN_ENULL;
     hipStream_t s = (hipStream_t)stream;
-    BY_NW(g, (k_predict_random<1><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, key, step, step_dev, lane_offset, actions)),
-          (k_predict_random<2><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, key, step, step_dev, lane_offset, actions)));
+    BY_NW(g, (k_predict_random<1><<<GRID(M), BS, (size_t)BS * g.cells, s>>>(g, M, boards, dice, key, step, step_dev, lane_offset, actions)),
+          (k_predict_random<2><<<GRID(M), BS, (size_t)BS * g.cells, s>>>(g, M, boards, dice, key, step, step_dev, lane_offset, actions)));
     return launch_status();
 }
 

@@ -321,7 +321,8 @@ __device__ void d3_reset(const FastTab<S> *Tb, const D3Cfg &c, u32 seed, u32 *wi
 
 // EinsteinWuerfeltNichtEnv.step (envs/ewn.py:436-486), minimax(depth 3, hybrid) opponent, cube_layer 3.
 // T lanes per game; lanes of a group run identical code on identical data except inside d3_search.
-template <int S, int T>
+// OPP 0: ExpectiMinimaxAgent(max_depth=3, 'hybrid') reply;  OPP 1: RandomAgent reply (classical_policies/random_policy.py:11-15)
+template <int S, int T, int OPP>
 __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
 {
     constexpr int CELLS = S * S, GPB = D3_BS / T; // games per block
@@ -373,10 +374,28 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
     // the opponent's search: run by every lane (lanes without a pending reply compute on a harmless state),
     // so the DPP exchanges inside always see their partners
     int oflag = 0, odir = 0;
-    d3_search<S, T>(Tb, s, dice, sub, oflag, odir);
+    if constexpr (OPP == 0) d3_search<S, T>(Tb, s, dice, sub, oflag, odir);
     if (reply) {
         // opponent half, envs/ewn.py:464-486
         const CubeSel cs = select_cubes(s.aliveP, dice);
+        if constexpr (OPP == 1) {
+            // uniform index into the opponent's legal list (reference order: larger-neighbour cube first, dirs ascending),
+            // drawn from the lane's own dice stream like the reference's shared global stream
+            const bool have0 = cs.exact || cs.has_up, have1 = !cs.exact && cs.has_down;
+            const int p0 = pk_get(s.posP, have0 ? (cs.exact ? cs.k_exact : cs.k_up) : 0), p1 = pk_get(s.posP, have1 ? cs.k_down : 0);
+            u32 okm = 0;
+            #pragma unroll
+            for (int d = 0; d < 3; d++) {
+                okm |= ((have0 && Tb->nbp[d][p0] != 255) ? 1u : 0u) << d;
+                okm |= ((have1 && Tb->nbp[d][p1] != 255) ? 1u : 0u) << (3 + d);
+            }
+            const int pick = r.randint(0, __popc(okm));
+            u32 m = okm;
+            for (int i = 0; i < pick; i++) m &= m - 1;   // drop the `pick` lowest set bits
+            const int slot = __ffs((int)m) - 1;           // 0..5 = cube slot * 3 + dir
+            oflag = slot < 3 ? (cs.exact ? 0 : 1) : 0;
+            odir = slot < 3 ? slot : slot - 3;
+        }
         const int k = cube_to_move(cs, oflag == 1);
         const int q = Tb->nbp[odir][pk_get(s.posP, k)];
         rs_move<S>(s, true, k, q);

@@ -22,7 +22,8 @@
  *  - Boards are int8, row-major [lane][row][col], value k>0 = TOP_LEFT cube k,
  *    k<0 = BOTTOM_RIGHT cube |k|, 0 = empty (envs/ewn.py:49-58, 94-107).
  *  - Actions are int8 [lane][2] = {chose_larger in {0,1}, direction in {0,1,2}}
- *    (envs/ewn.py:61-62, 436-442).
+ *    (envs/ewn.py:61-62, 436-442); action buffers are 2-byte aligned, board / rng
+ *    / table buffers 16-byte aligned (any torch allocation is).
  */
 #ifndef EWN_HIP_H
 #define EWN_HIP_H
