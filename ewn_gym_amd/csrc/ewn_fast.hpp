@@ -26,15 +26,15 @@
 #pragma once
 #include "ewn_core.hpp"
 
-#define FAST_NV 1024   // distinct leaf values (incl. +-10) must fit 10-bit ranks; rank 1023 = "no such reply"
-#define FAST_NONE 0x3FFFFFFFu
+#define FAST_NV 1024   // distinct leaf values (incl. +-10) get ranks 1..nv in 10 bits; 0 = "none", 1023 = "no such reply"
+#define FAST_NONE 1023u // packed (cut << 10 | p2) of a cube that is not on the board
 
 template <int S>
 struct FastTab {
     static constexpr int IXN = S * 8;            // index of one side's (level t, count n): t*8 + n, n <= 6
     static constexpr int CELLS = S * S;
-    uint16_t rank[IXN * IXN];                    // [ix(P side)][iy(N side)] -> rank of (0 + x) - y
-    double val[FAST_NV];                         // rank -> leaf value (ascending)
+    uint16_t rank[IXN * IXN];                    // [ix(P side)][iy(N side)] -> rank of (0 + x) - y: 1 = lowest value (-10) ... nv
+    double val[FAST_NV];                         // rank -> leaf value (ascending); val[0] = -inf (rank 0 = "none"), unused ranks = +inf
     double val6[FAST_NV];                        // rank -> value / 6.0 (IEEE quotient, host-computed)
     uint16_t lutx[72];                           // clz(P mask) -> t*8*IXN   (entry for an empty mask: 0)
     uint16_t luty[72];                           // clz(N mask) -> t*8
@@ -59,120 +59,6 @@ EWN_DEV int clz_m(u32 m) { return __clz((int)m); }       // 32 for m == 0
 EWN_DEV int clz_m(u64 m) { return __clzll((long long)m); } // 64 for m == 0
 EWN_DEV int popc_m(u32 m) { return __popc(m); }
 EWN_DEV int popc_m(u64 m) { return __popcll(m); }
-
-// Depth-3 hybrid search on a CANONICAL position (TOP_LEFT = positive side to move).
-// T lives in LDS.  Returns the root value; action in (bflag, bdir).  cube_layer == 3.
-template <int S>
-__device__ __forceinline__ double fast_d3(const FastTab<S> *T, const GState<1> &c, int dice, int &bflag, int &bdir)
-{
-    typedef typename MaskOf<S>::type M;
-    constexpr int IXN = FastTab<S>::IXN;
-    const M one = 1;
-
-    // ---- ring-order masks and positions
-    M P = 0, N = 0;
-    int rn[6];
-    #pragma unroll
-    for (int k = 0; k < 6; k++) {
-        const int rp = T->ri[pos_get<1>(c.posP, k)];
-        if ((c.aliveP >> k) & 1u) P |= one << rp;
-        rn[k] = T->ri[pos_get<1>(c.posN, k)];
-        if ((c.aliveN >> k) & 1u) N |= one << rn[k];
-    }
-
-    // ---- the replier's 18 (cube, dir) moves never change during the search
-    M rset[6][3], rclr[6];
-    u32 legal = 0, hits_origin = 0; // bit k*3+dir
-    #pragma unroll
-    for (int k = 0; k < 6; k++) {
-        rclr[k] = ~(one << rn[k]);
-        #pragma unroll
-        for (int d = 0; d < 3; d++) {
-            const int dn = T->nbn[d][rn[k]];
-            const bool ok = dn != 255;
-            rset[k][d] = ok ? (one << dn) : (M)0;
-            legal |= (ok ? 1u : 0u) << (k * 3 + d);
-            hits_origin |= ((ok && dn == T->ri_origin) ? 1u : 0u) << (k * 3 + d);
-        }
-    }
-
-    // ---- root slots: <= 2 cubes x 3 dirs in the reference's list order (envs/ewn.py:338-375)
-    const CubeSel cs = select_cubes(c.aliveP, dice);
-    const bool have0 = cs.exact || cs.has_up, have1 = !cs.exact && cs.has_down;
-    const int k0 = cs.exact ? cs.k_exact : cs.k_up, k1 = cs.k_down;
-    const int flag0 = cs.exact ? 0 : 1;
-    const int rp0 = T->ri[pos_get<1>(c.posP, have0 ? k0 : 0)], rp1 = T->ri[pos_get<1>(c.posP, have1 ? k1 : 0)];
-
-    double best = -__builtin_inf(); // alpha = max(alpha, best_val) is simply the running best (root beta stays +inf)
-    bflag = 0; bdir = 0;
-
-    #pragma unroll
-    for (int r = 0; r < 6; r++) {
-        const int slot = r / 3, dir = r % 3;
-        const int rp = slot == 0 ? rp0 : rp1;
-        const int dest = T->nbp[dir][rp];
-        const bool valid = (slot == 0 ? have0 : have1) && dest != 255;
-        const M bd = valid ? (one << dest) : (M)0;
-        const M P1 = (P & ~(one << rp)) | bd; // own capture: the bit is already set, the count drops by itself
-        const M N1 = N & ~bd;
-        // win(B1): evaluate(B1) = 10, envs/minimax_ewn.py:42-44.  The leaf work below runs regardless
-        // (predicated, no branch) so the scheduler can overlap the LDS reads of all 18 leaves.
-        const bool term = dest == FastTab<S>::CELLS - 1 || N1 == 0;
-        // leaves of this root: replier cube k (alive in B1) x dir -> packed prefix minima of ranks
-        u32 tr[6];
-        #pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const bool alive1 = ((c.aliveN >> k) & 1u) && rn[k] != dest;
-            const M Nk = N1 & rclr[k];
-            u32 a[3];
-            #pragma unroll
-            for (int d = 0; d < 3; d++) {
-                const M N2 = Nk | rset[k][d];
-                const M P2 = P1 & ~rset[k][d];
-                const int ix = T->lutx[clz_m(P2)] + popc_m(P2) * IXN;
-                const int iy = T->luty[clz_m(N2)] + popc_m(N2);
-                u32 rk = T->rank[ix + iy];
-                rk = (P2 == 0 || ((hits_origin >> (k * 3 + d)) & 1u)) ? 0u : rk;   // -10: envs/minimax_ewn.py:45-47
-                a[d] = (alive1 && ((legal >> (k * 3 + d)) & 1u)) ? rk : 1023u;
-            }
-            const u32 p1 = min(a[0], a[1]), p2 = min(p1, a[2]);
-            tr[k] = a[0] | (p1 << 10) | (p2 << 20);
-        }
-        // which cubes a dice value selects (find_near_cube): carry the nearest alive cube's data along
-        u32 upT[6], downT[6];
-        {
-            u32 cur = FAST_NONE;
-            #pragma unroll
-            for (int d = 5; d >= 0; d--) { upT[d] = cur; cur = tr[d] != FAST_NONE ? tr[d] : cur; }
-            cur = FAST_NONE;
-            #pragma unroll
-            for (int d = 0; d < 6; d++) { downT[d] = cur; cur = tr[d] != FAST_NONE ? tr[d] : cur; }
-        }
-        double v = 0.0;
-        #pragma unroll
-        for (int d = 0; d < 6; d++) {
-            const bool exact = tr[d] != FAST_NONE;
-            const bool up = upT[d] != FAST_NONE;
-            const u32 F = exact ? tr[d] : (up ? upT[d] : downT[d]);
-            const u32 G = (!exact && up) ? downT[d] : FAST_NONE;
-            const int x0 = (int)(F & 1023u), x1 = (int)((F >> 10) & 1023u), x2 = (int)(F >> 20);
-            const int y0 = min(x2, (int)(G & 1023u)), y1 = min(x2, (int)((G >> 10) & 1023u)), y2 = min(x2, (int)(G >> 20));
-            // `worst <= alpha` (minimax.py:59-61) against alpha = best so far; val[1023] = +inf marks "no such reply"
-            int w = y2; // the full minimum: what the loop returns when it never breaks
-            w = max(w, T->val[x0] <= best ? x0 : 0);
-            w = max(w, T->val[x1] <= best ? x1 : 0);
-            w = max(w, T->val[x2] <= best ? x2 : 0);
-            w = max(w, T->val[y0] <= best ? y0 : 0);
-            w = max(w, T->val[y1] <= best ? y1 : 0);
-            v = v + T->val6[w]; // expected_val += val / 6, minimax.py:72
-        }
-        v = term ? 10.0 : v;
-        if (valid && v > best) {
-            best = v; bflag = slot == 0 ? flag0 : 0; bdir = dir;
-        }
-    }
-    return best;
-}
 
 // ---------------------------------------------------------------- host: table construction
 #include <algorithm>
@@ -240,17 +126,17 @@ static int build_fast_tables(FastTab<S> *T)
     all.push_back(10.0);
     std::sort(all.begin(), all.end());
     all.erase(std::unique(all.begin(), all.end()), all.end());
-    if ((int)all.size() > FAST_NV - 1) return -1;
+    if ((int)all.size() > FAST_NV - 3) return -1;
     T->nv = (int)all.size();
     for (int i = 0; i < FAST_NV; i++) {
-        const double v = i < T->nv ? all[i] : __builtin_inf(); // unused ranks compare above every alpha
+        const double v = i == 0 ? -__builtin_inf() : (i <= T->nv ? all[i - 1] : __builtin_inf()); // unused ranks compare above every alpha
         volatile double q = v / 6.0;
         T->val[i] = v; T->val6[i] = q;
     }
     for (int ix = 0; ix < IXN; ix++)
         for (int iy = 0; iy < IXN; iy++) {
             const bool used = (ix % 8) >= 1 && (ix % 8) <= 6 && (iy % 8) >= 1 && (iy % 8) <= 6;
-            T->rank[ix * IXN + iy] = used ? (uint16_t)(std::lower_bound(all.begin(), all.end(), e[(size_t)ix * IXN + iy]) - all.begin()) : 0;
+            T->rank[ix * IXN + iy] = used ? (uint16_t)(1 + (std::lower_bound(all.begin(), all.end(), e[(size_t)ix * IXN + iy]) - all.begin())) : 1;
         }
     return 0;
 }

@@ -144,7 +144,9 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
         const M N1 = c.N & ~bd;
         const bool term = dest == FastTab<S>::CELLS - 1 || N1 == 0; // win(B1): value 10
 
-        // my leaves -> packed prefix minima of ranks per cube
+        // my leaves -> per cube: full minimum p2 and `cut` = the value at which the reference's reply loop would stop
+        // inside this cube's replies (`worst <= alpha`, minimax.py:59-61; alpha = best so far), 0 if it would not.
+        // The running minimum along a cube's replies is non-increasing, so the first one <= alpha is the largest one <= alpha.
         u32 tr[6];
         #pragma unroll
         for (int i = 0; i < KPT; i++) {
@@ -158,11 +160,14 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
                 const int ix = Tb->lutx[clz_m(P2)] + popc_m(P2) * IXN;
                 const int iy = Tb->luty[clz_m(N2)] + popc_m(N2);
                 u32 rk = Tb->rank[ix + iy];
-                rk = (P2 == 0 || ((hits_origin >> (i * 3 + d)) & 1u)) ? 0u : rk;   // -10: envs/minimax_ewn.py:45-47
+                rk = (P2 == 0 || ((hits_origin >> (i * 3 + d)) & 1u)) ? 1u : rk;   // -10 (rank 1): envs/minimax_ewn.py:45-47
                 a[d] = (alive1 && ((legal >> (i * 3 + d)) & 1u)) ? rk : 1023u;
             }
             const u32 p1 = min(a[0], a[1]), p2 = min(p1, a[2]);
-            const u32 mine = a[0] | (p1 << 10) | (p2 << 20);
+            u32 cut = Tb->val[a[0]] <= best ? a[0] : 0u;       // val[1023] = +inf: an absent reply never cuts
+            cut = max(cut, Tb->val[p1] <= best ? p1 : 0u);
+            cut = max(cut, Tb->val[p2] <= best ? p2 : 0u);
+            const u32 mine = p2 | (cut << 10);                 // a cube that is off the board: p2 = 1023, cut = 0 -> FAST_NONE
             // publish to the group: after this every lane holds tr[k] for all six cubes (cube k = j + T*i lives in lane j)
             if constexpr (T == 1) tr[i] = mine;
             else if constexpr (T == 2) { tr[2 * i] = dpp_u32<Bcast<2, 0>::CTRL>(mine); tr[2 * i + 1] = dpp_u32<Bcast<2, 1>::CTRL>(mine); }
@@ -172,7 +177,7 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
                 else { tr[4] = dpp_u32<Bcast<4, 0>::CTRL>(mine); tr[5] = dpp_u32<Bcast<4, 1>::CTRL>(mine); }
             }
         }
-        // which cubes a dice value selects (find_near_cube): carry the nearest alive cube's data along
+        // which cubes a dice value selects (find_near_cube): carry the nearest on-board cube's data along
         u32 upT[6], downT[6];
         {
             u32 cur = FAST_NONE;
@@ -182,33 +187,26 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
             #pragma unroll
             for (int d = 0; d < 6; d++) { downT[d] = cur; cur = tr[d] != FAST_NONE ? tr[d] : cur; }
         }
-        // the (first, second) reply cubes of every dice value (get_legal_actions order: larger neighbour first)
-        u32 Fd[6], Gd[6];
-        #pragma unroll
-        for (int d = 0; d < 6; d++) {
-            const bool exact = tr[d] != FAST_NONE;
-            const bool up = upT[d] != FAST_NONE;
-            Fd[d] = exact ? tr[d] : (up ? upT[d] : downT[d]);
-            Gd[d] = (!exact && up) ? downT[d] : FAST_NONE;
-        }
-        // my share of the six chance branches: dice index d = sub + T*i
+        // my share of the six chance branches: dice index d = sub + T*i.  Reply order is the larger-neighbour cube F, then
+        // the smaller-neighbour cube G (get_legal_actions): the loop stops in F if F cuts, else in G if G cuts, else
+        // it returns the minimum over both.
         double q[6];
         #pragma unroll
         for (int i = 0; i < KPT; i++) {
             u32 F = FAST_NONE, G = FAST_NONE;
             #pragma unroll
-            for (int j = 0; j < T; j++)
-                if (T * i + j < 6) { F = sub == j ? Fd[T * i + j] : F; G = sub == j ? Gd[T * i + j] : G; }
-            const int x0 = (int)(F & 1023u), x1 = (int)((F >> 10) & 1023u), x2 = (int)(F >> 20);
-            const int y0 = min(x2, (int)(G & 1023u)), y1 = min(x2, (int)((G >> 10) & 1023u)), y2 = min(x2, (int)(G >> 20));
-            // `worst <= alpha` (minimax.py:59-61) vs alpha = best so far; val[1023] = +inf marks "no such reply"
-            int w = y2;
-            w = max(w, Tb->val[x0] <= best ? x0 : 0);
-            w = max(w, Tb->val[x1] <= best ? x1 : 0);
-            w = max(w, Tb->val[x2] <= best ? x2 : 0);
-            w = max(w, Tb->val[y0] <= best ? y0 : 0);
-            w = max(w, Tb->val[y1] <= best ? y1 : 0);
-            const double mine = Tb->val6[min(w, 1023)];
+            for (int j = 0; j < T; j++) {
+                const int d = T * i + j;
+                if (d < 6) {
+                    const bool exact = tr[d] != FAST_NONE, up = upT[d] != FAST_NONE;
+                    const u32 Fd = exact ? tr[d] : (up ? upT[d] : downT[d]);
+                    const u32 Gd = (!exact && up) ? downT[d] : FAST_NONE;
+                    F = (T == 1 || sub == j) ? Fd : F; G = (T == 1 || sub == j) ? Gd : G;
+                }
+            }
+            const u32 cutF = F >> 10, cutG = G >> 10;
+            const u32 w = cutF ? cutF : (cutG ? cutG : min(F & 1023u, G & 1023u));
+            const double mine = Tb->val6[w];
             if constexpr (T == 1) q[i] = mine;
             else if constexpr (T == 2) { q[2 * i] = dpp_f64<Bcast<2, 0>::CTRL>(mine); q[2 * i + 1] = dpp_f64<Bcast<2, 1>::CTRL>(mine); }
             else {
@@ -224,6 +222,22 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
         if (valid && v > best) { best = v; bflag = slot == 0 ? flag0 : 0; bdir = dir; }
     }
     return best;
+}
+
+// The same search from a row-major canonical GState (stateless predict kernel, generic step kernel's fast path)
+template <int S>
+__device__ __forceinline__ double fast_d3(const FastTab<S> *Tb, const GState<1> &c, int dice, int &bflag, int &bdir)
+{
+    typedef typename MaskOf<S>::type M;
+    RState<S> s;
+    s.P = 0; s.N = 0; s.posP = 0; s.posN = 0; s.aliveP = c.aliveP & 63u; s.aliveN = c.aliveN & 63u;
+    #pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int rp = Tb->ri[pos_get<1>(c.posP, k)], rn = Tb->ri[pos_get<1>(c.posN, k)];
+        if ((c.aliveP >> k) & 1u) { s.P |= (M)1 << rp; s.posP |= (u64)rp << (6 * k); }
+        if ((c.aliveN >> k) & 1u) { s.N |= (M)1 << rn; s.posN |= (u64)rn << (6 * k); }
+    }
+    return d3_search<S, 1>(Tb, s, dice, 0, bflag, bdir);
 }
 
 // ---------------------------------------------------------------- the fused step kernel
