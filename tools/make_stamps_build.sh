@@ -18,4 +18,4 @@ s=s.replace("    __syncthreads();\n    block_copy_out(B.board + (size_t)g0 * CEL
 print("stamps inserted:", s.count("STAMP(")-n0)
 open(p,'w').write(s)
 PY
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -o /root/repo/ewn_gym_amd/lib/libewn_hip_stamps.so ewn_kernels.hip -save-temps=obj
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -o /root/repo/ewn_gym_amd/lib/libewn_hip_stamps.so ewn_kernels.hip
