@@ -375,7 +375,18 @@ __device__ __noinline__ u32 mt_output_closed(u32 seed, u32 n)
 EWN_DEV uint4 *rng_hdr_ptr(u32 *rng, int lane) { return (uint4 *)rng + lane; }
 EWN_DEV u32 *rng_win_ptr(u32 *rng, int N, u32 W, int lane) { return rng + (size_t)N * EWN_RNG_HDR + (size_t)lane * W; }
 
+EWN_DEV u32 fmix32(u32 h) // MurmurHash3 finaliser
+{
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+
 // One lane's dice stream for the duration of a kernel.
+//  kind 0 (MT19937): np.random.seed / legacy randint, bit-exact with the reference.
+//  kind 1 (Philox):  word n of an episode = philox4x32-10(ctr={n>>2, seed, 0, 'ENV1'}, key)[n&3].  A step starts on a
+//                    block boundary and needs <= 3 words (opponent dice, random opponent's choice, next dice), so ONE
+//                    Philox block serves a step; bounded draws use Lemire's multiply-shift (exact: the rare rejection
+//                    re-draws); an episode's first dice is a hash of its seed, so reset() needs no second block.
 struct LaneRng {
     int kind;         // 0 MT19937 window, 1 Philox
     u32 seed, n, next_seed, flags;
@@ -401,8 +412,27 @@ struct LaneRng {
     }
     // np.random.randint(lo, hi) of the legacy RandomState: masked rejection on 32-bit
     // draws; a one-element range consumes no draw.
+    EWN_DEV void begin_step() { if (kind == 1) ps.n = (ps.n + 3u) & ~3u; }
+    EWN_DEV int first_dice(int cube_num)
+    {
+        if (kind != 1) return randint(1, cube_num + 1);      // roll_dice, envs/ewn.py:90-91
+        const u32 w = fmix32(seed ^ fmix32(ps.k0 ^ 0x454E5631u) ^ (ps.k1 * 0x9E3779B1u));
+        return 1 + (int)__umulhi(w, (u32)cube_num);           // bias <= cube_num / 2^32
+    }
+    EWN_DEV int lemire(u32 range)
+    {
+        if (range <= 1u) return 0;
+        u64 m = (u64)next() * range;
+        if ((u32)m < range) {                                  // probability range / 2^32
+            const u32 t = (0u - range) % range;
+            int guard = 0;
+            while ((u32)m < t && ++guard < 64) m = (u64)next() * range;
+        }
+        return (int)(m >> 32);
+    }
     EWN_DEV int randint(int lo, int hi)
     {
+        if (kind == 1) return lo + lemire((u32)(hi - lo));
         const u32 rng = (u32)(hi - lo - 1);
         if (rng == 0) return lo;
         u32 mask = rng;

@@ -83,7 +83,7 @@ __device__ void lane_reset(const Geom &g, const KCfg &c, u32 seed, u32 *win, GSt
     if (c.rng_kind == 0) mt_fill_window(seed, (int)c.W, win);
     r.load(c.rng_kind, make_uint4(seed, 0u, seed + c.seed_stride, 0u), win, c.W, c.key);
     init_state<NW>(g, s);
-    dice = r.randint(1, g.CN + 1); // roll_dice :90-91
+    dice = r.first_dice(g.CN); // roll_dice :90-91
 }
 
 struct StepRes { double reward; int term, trunc, info; };
@@ -254,6 +254,7 @@ __global__ __launch_bounds__(BS) void k_step(Geom g, KCfg c, KState st, const in
             } else {
                 u32 *win = rng_win_ptr(st.rng, c.N, c.W, lane);
                 LaneRng r; r.load(c.rng_kind, hdr, win, c.W, c.key);
+                if (PHASE != 2) r.begin_step();
                 GState<NW> s;
                 decode_board<NW>(g, mine, s);
                 bool reply;

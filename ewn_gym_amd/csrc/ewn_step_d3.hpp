@@ -330,7 +330,7 @@ __device__ void d3_reset(const FastTab<S> *Tb, const D3Cfg &c, u32 seed, u32 *wi
     if (c.rng_kind == 0) mt_fill_window(seed, (int)c.W, win);
     r.load(c.rng_kind, make_uint4(seed, 0u, seed + c.seed_stride, 0u), win, c.W, c.key);
     d3_init_state<S>(Tb, s);
-    dice = r.randint(1, 7);
+    dice = r.first_dice(6);
 }
 
 // EinsteinWuerfeltNichtEnv.step (envs/ewn.py:436-486), minimax(depth 3, hybrid) opponent, cube_layer 3.
@@ -369,6 +369,7 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
     RState<S> s;
     u32 *win = rng_win_ptr(B.rng, c.N, c.W, live ? game : 0);
     LaneRng r; r.load(c.rng_kind, hdr, win, c.W, c.key);
+    r.begin_step();
     d3_decode<S, T>(live ? mine : lds, sub, s); // every lane takes part (DPP combine); non-live lanes read game 0 of the block
     const bool active = live && !frozen;
     bool reply = false;

@@ -53,22 +53,25 @@ def test_a2c_learns_to_avoid_illegal_moves():
     env = ea.VecEWN(N, opponent_policy="random", rng="philox", shaped=True, reward=10.0, illegal_move_reward=-1.0,
                     illegal_move_tolerance=10, autoreset=True, shaped_refresh_on_reset=True, philox_key=1)
     env.reset(seeds=torch.arange(N, dtype=torch.int32))
-    tr = A2CTrainer(env, n_steps=5, learning_rate=3e-3, seed=0)
+    tr = A2CTrainer(env, n_steps=5, learning_rate=1e-3, seed=0)
     p0 = [p.detach().clone() for p in tr.model.parameters()]
 
-    def illegal_rate():
-        a, _ = tr.model.act(env.board, env.dice, deterministic=False, generator=tr.gen)
-        acts, n, _, _, _ = ea.legal_actions(env.board, env.dice, player=1)
-        ok = ((acts[:, :, 0] == a[:, None, 0]) & (acts[:, :, 1] == a[:, None, 1])).any(1)
-        # flag is ignored when the dice cube is alive: count a move legal if its direction is legal for the cube that would move
-        return 1.0 - float(ok.float().mean().item())
+    def illegal_rate(steps=12):
+        """fraction of env transitions the env itself flags as illegal agent moves (info codes 1 and 5)"""
+        bad = tot = 0
+        for _ in range(steps):
+            a, _ = tr.model.act(env.board, env.dice, deterministic=False, generator=tr.gen)
+            info = env.step(a)[5]
+            bad += int(((info == 1) | (info == 5)).sum().item())
+            tot += N
+        return bad / tot
 
     before = illegal_rate()
     stats = None
-    for _ in range(150):
+    for _ in range(300):
         stats = tr.collect_and_update()
     after = illegal_rate()
     assert all(np.isfinite(v) for v in stats.values())
     assert any(not torch.equal(a, b) for a, b in zip(p0, tr.model.parameters()))
-    assert tr.num_timesteps == 150 * 5 * N
-    assert after < before - 0.05, (before, after)
+    assert tr.num_timesteps == 300 * 5 * N
+    assert after < 0.6 * before, (before, after)
