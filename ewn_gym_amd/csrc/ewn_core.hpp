@@ -298,19 +298,21 @@ EWN_DEV void philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u32 k0, u32 k1, u32 (
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// Sequential u32 stream: word n = philox(ctr={n>>2, c1, c2, c3}, key)[n&3]
+// Sequential u32 stream: word n = philox(ctr={n>>2, c1, c2, c3}, key)[n&3].
+// The cached block is four scalars, not an array: an array indexed by (n & 3) ends up in scratch memory.
 struct PhiloxStream {
     u32 c1, c2, c3, k0, k1, n;
-    u32 blk[4];
+    u32 b0, b1, b2, b3;
     u32 have; // block index + 1 currently cached (0 = none)
-    EWN_DEV void init(u32 c1_, u32 c2_, u32 c3_, u64 key, u32 n_) { c1 = c1_; c2 = c2_; c3 = c3_; k0 = (u32)key; k1 = (u32)(key >> 32); n = n_; have = 0; }
+    EWN_DEV void init(u32 c1_, u32 c2_, u32 c3_, u64 key, u32 n_) { c1 = c1_; c2 = c2_; c3 = c3_; k0 = (u32)key; k1 = (u32)(key >> 32); n = n_; have = 0; b0 = b1 = b2 = b3 = 0; }
     EWN_DEV u32 next()
     {
         const u32 b = n >> 2;
-        if (have != b + 1) { philox4x32_10(b, c1, c2, c3, k0, k1, blk); have = b + 1; }
-        const u32 i = n & 3u;
+        if (have != b + 1) { u32 o[4]; philox4x32_10(b, c1, c2, c3, k0, k1, o); b0 = o[0]; b1 = o[1]; b2 = o[2]; b3 = o[3]; have = b + 1; }
+        const u32 i = n;
         n++;
-        return i == 0 ? blk[0] : (i == 1 ? blk[1] : (i == 2 ? blk[2] : blk[3]));
+        const u32 lo = (i & 1u) ? b1 : b0, hi = (i & 1u) ? b3 : b2;
+        return (i & 2u) ? hi : lo;
     }
 };
 

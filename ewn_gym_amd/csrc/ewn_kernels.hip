@@ -78,7 +78,7 @@ __device__ __forceinline__ void tables_to_lds(int8_t *lds, const int8_t *g)
 
 // reset(seed) + setup_game, envs/ewn.py:488-494, 94-108
 template <int NW>
-__device__ void lane_reset(const Geom &g, const KCfg &c, u32 seed, u32 *win, GState<NW> &s, int &dice, LaneRng &r)
+EWN_DEV void lane_reset(const Geom &g, const KCfg &c, u32 seed, u32 *win, GState<NW> &s, int &dice, LaneRng &r)
 {
     if (c.rng_kind == 0) mt_fill_window(seed, (int)c.W, win);
     r.load(c.rng_kind, make_uint4(seed, 0u, seed + c.seed_stride, 0u), win, c.W, c.key);
@@ -91,7 +91,7 @@ struct StepRes { double reward; int term, trunc, info; };
 // Agent half of step(): envs/ewn.py:438-458 and training_ewn.py:44-66.
 // Returns true when the opponent must still reply.
 template <int NW>
-__device__ bool step_agent(const Geom &g, const KCfg &c, GState<NW> &s, int &dice, int flag, int dir, LaneRng &r,
+EWN_DEV bool step_agent(const Geom &g, const KCfg &c, GState<NW> &s, int &dice, int flag, int dir, LaneRng &r,
                            int32_t *tol, StepRes &o)
 {
     o.reward = 0.0; o.term = 0; o.trunc = 0; o.info = EWN_INFO_NONE;
@@ -115,7 +115,7 @@ __device__ bool step_agent(const Geom &g, const KCfg &c, GState<NW> &s, int &dic
 
 // Opponent half: envs/ewn.py:464-486, training_ewn.py:75-99.
 template <int NW>
-__device__ void step_opponent(const Geom &g, const KCfg &c, GState<NW> &s, int &dice, int oflag, int odir, LaneRng &r,
+EWN_DEV void step_opponent(const Geom &g, const KCfg &c, GState<NW> &s, int &dice, int oflag, int odir, LaneRng &r,
                               double *prev_score, StepRes &o)
 {
     const CubeSel cs = select_cubes(s.aliveN, dice);
@@ -135,7 +135,7 @@ __device__ void step_opponent(const Geom &g, const KCfg &c, GState<NW> &s, int &
 // RandomAgent.predict on the live env (classical_policies/random_policy.py:11-15):
 // uniform index into BOTTOM_RIGHT's legal list, drawn from the lane's own stream.
 template <int NW>
-__device__ void policy_random(const Geom &g, const GState<NW> &s, int dice, LaneRng &r, int &oflag, int &odir)
+EWN_DEV void policy_random(const Geom &g, const GState<NW> &s, int dice, LaneRng &r, int &oflag, int &odir)
 {
     const int n = for_each_legal<1, NW>(g, s, dice, [](int, int, int) { return true; });
     const int pick = r.randint(0, n);

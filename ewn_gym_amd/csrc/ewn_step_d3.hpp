@@ -324,7 +324,7 @@ EWN_DEV void d3_init_state(const FastTab<S> *Tb, RState<S> &s)
 
 // reset(seed) + setup_game (envs/ewn.py:488-494, 94-108)
 template <int S>
-__device__ void d3_reset(const FastTab<S> *Tb, const D3Cfg &c, u32 seed, u32 *win, RState<S> &s, int &dice, LaneRng &r)
+EWN_DEV void d3_reset(const FastTab<S> *Tb, const D3Cfg &c, u32 seed, u32 *win, RState<S> &s, int &dice, LaneRng &r)
 {
     // all T lanes of the group fill the window with identical values (each lane only ever reads back its own stores)
     if (c.rng_kind == 0) mt_fill_window(seed, (int)c.W, win);
