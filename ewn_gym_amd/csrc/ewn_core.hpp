@@ -370,12 +370,20 @@ __device__ __noinline__ u32 mt_output_closed(u32 seed, u32 n)
     return mt_temper(x397 ^ mt_twist(sn, sn1));
 }
 
-#define EWN_RNG_HDR 4 // header words per lane: seed, draw index, next_seed, flags(bit0 = MT draw index >= 454: unsupported)
+#define EWN_RNG_HDR 4 // header words per lane: seed, draw index, next_seed, flags
+#define RNGF_OVERFLOW 1u  // MT draw index >= 454 in one episode: unsupported (never observed)
+#define RNGF_SLOT 2u      // which of the lane's two MT windows belongs to the current episode
+#define RNGF_SPARE 4u     // the other window already holds the outputs for seed `next_seed`
+#define RNGF_NEED 8u      // the spare window was consumed by an auto-reset: k_mt_refill must rebuild it
 
-// ewn_state.rng holds N headers (uint4 each, one coalesced 16-byte access per lane) followed by
-// N windows of W tempered MT19937 outputs (MT kind only).
+// ewn_state.rng holds N headers (uint4 each, one coalesced 16-byte access per lane) followed, for the MT kind, by
+// N x 2 windows of W tempered MT19937 outputs: the current episode's and, prepared ahead of time by k_mt_refill,
+// the next episode's -- so an auto-reset inside the step kernel is a slot flip, not a 500-step recurrence.
 EWN_DEV uint4 *rng_hdr_ptr(u32 *rng, int lane) { return (uint4 *)rng + lane; }
-EWN_DEV u32 *rng_win_ptr(u32 *rng, int N, u32 W, int lane) { return rng + (size_t)N * EWN_RNG_HDR + (size_t)lane * W; }
+EWN_DEV u32 *rng_win_ptr(u32 *rng, int N, u32 W, int lane, u32 flags)
+{
+    return rng + (size_t)N * EWN_RNG_HDR + ((size_t)lane * 2 + ((flags & RNGF_SLOT) ? 1 : 0)) * W;
+}
 
 EWN_DEV u32 fmix32(u32 h) // MurmurHash3 finaliser
 {
@@ -395,9 +403,19 @@ struct LaneRng {
     u32 W;
     const u32 *win;
     PhiloxStream ps;
+    // MT kind: the next 8 window words, fetched in one round trip when the lane is loaded, so the masked-rejection
+    // loop of randint does not serialise a global load per iteration (scalars, not an array: no scratch)
+    u32 pre_base, p0, p1, p2, p3, p4, p5, p6, p7;
+    EWN_DEV void prefetch()
+    {
+        pre_base = n;
+        if (kind == 0 && n + 8u <= W) { p0 = win[n]; p1 = win[n + 1]; p2 = win[n + 2]; p3 = win[n + 3]; p4 = win[n + 4]; p5 = win[n + 5]; p6 = win[n + 6]; p7 = win[n + 7]; }
+        else pre_base = 0xFFFFFFF0u; // nothing cached
+    }
     EWN_DEV void load(int kind_, uint4 h, const u32 *win_, u32 W_, u64 key)
     {
         kind = kind_; seed = h.x; n = h.y; next_seed = h.z; flags = h.w; W = W_; win = win_;
+        p0 = p1 = p2 = p3 = p4 = p5 = p6 = p7 = 0; pre_base = 0xFFFFFFF0u;
         if (kind == 1) ps.init(seed, 0u, 0x454E5631u, key, n);
     }
     EWN_DEV uint4 header() const { return make_uint4(seed, kind == 1 ? ps.n : n, next_seed, flags); }
@@ -406,14 +424,36 @@ struct LaneRng {
     {
         if (kind == 1) return ps.next();
         u32 v;
-        if (n < W) v = win[n];
+        const u32 j = n - pre_base;
+        if (j < 8u) {
+            const u32 a = (j & 1u) ? p1 : p0, b = (j & 1u) ? p3 : p2, c = (j & 1u) ? p5 : p4, d = (j & 1u) ? p7 : p6;
+            const u32 ab = (j & 2u) ? b : a, cd = (j & 2u) ? d : c;
+            v = (j & 4u) ? cd : ab;
+        }
+        else if (n < W) v = win[n];
         else if (n < 454u) v = mt_output_closed(seed, n);
-        else { v = 0; flags |= 1u; }
+        else { v = 0; flags |= RNGF_OVERFLOW; }
         n++;
         return v;
     }
     // np.random.randint(lo, hi) of the legacy RandomState: masked rejection on 32-bit
     // draws; a one-element range consumes no draw.
+    // Start the next episode (seed = next_seed).  MT kind: flip to the window prepared by k_mt_refill and flag the
+    // lane for the next refill; if the spare is not ready (auto-reset without refills in between) rebuild in place.
+    EWN_DEV void next_episode(u32 *rng, int N, int lane, u32 stride, u64 key)
+    {
+        const u32 s2 = next_seed;
+        u32 f = flags & ~RNGF_OVERFLOW;
+        if (kind == 0) {
+            if (f & RNGF_SPARE) {
+                f = ((f ^ RNGF_SLOT) & ~RNGF_SPARE) | RNGF_NEED;
+            } else {
+                mt_fill_window(s2, (int)W, rng_win_ptr(rng, N, W, lane, f));
+            }
+        }
+        load(kind, make_uint4(s2, 0u, s2 + stride, f), rng_win_ptr(rng, N, W, lane, f), W, key);
+        prefetch();
+    }
     EWN_DEV void begin_step() { if (kind == 1) ps.n = (ps.n + 3u) & ~3u; }
     EWN_DEV int first_dice(int cube_num)
     {

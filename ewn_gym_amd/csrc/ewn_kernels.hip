@@ -76,14 +76,58 @@ __device__ __forceinline__ void tables_to_lds(int8_t *lds, const int8_t *g)
 
 // ---------------------------------------------------------------- per-lane pieces
 
-// reset(seed) + setup_game, envs/ewn.py:488-494, 94-108
+// reset(seed) + setup_game, envs/ewn.py:488-494, 94-108, for an explicitly given seed: builds the window of this
+// episode and, ahead of time, of the next one (seed + stride)
 template <int NW>
-EWN_DEV void lane_reset(const Geom &g, const KCfg &c, u32 seed, u32 *win, GState<NW> &s, int &dice, LaneRng &r)
+EWN_DEV void lane_reset(const Geom &g, const KCfg &c, u32 *rng, int lane, u32 seed, GState<NW> &s, int &dice, LaneRng &r)
 {
-    if (c.rng_kind == 0) mt_fill_window(seed, (int)c.W, win);
-    r.load(c.rng_kind, make_uint4(seed, 0u, seed + c.seed_stride, 0u), win, c.W, c.key);
+    u32 f = 0;
+    if (c.rng_kind == 0) {
+        mt_fill_window(seed, (int)c.W, rng_win_ptr(rng, c.N, c.W, lane, 0u));
+        mt_fill_window(seed + c.seed_stride, (int)c.W, rng_win_ptr(rng, c.N, c.W, lane, RNGF_SLOT));
+        f = RNGF_SPARE;
+    }
+    r.load(c.rng_kind, make_uint4(seed, 0u, seed + c.seed_stride, f), rng_win_ptr(rng, c.N, c.W, lane, f), c.W, c.key);
     init_state<NW>(g, s);
     dice = r.first_dice(g.CN); // roll_dice :90-91
+}
+
+// the auto-reset inside a step: next_seed becomes the episode seed
+template <int NW>
+EWN_DEV void lane_auto_reset(const Geom &g, const KCfg &c, u32 *rng, int lane, const KScratch &sc, GState<NW> &s, int &dice, LaneRng &r)
+{
+    r.next_episode(rng, c.N, lane, c.seed_stride, c.key);
+    init_state<NW>(g, s);
+    dice = r.first_dice(g.CN);
+}
+
+// Rebuild the spare MT window of every lane whose header carries RNGF_NEED (set by an auto-reset): one thread per
+// lane, coalesced header reads, waves without a flagged lane leave at once.  The seeding recurrence (397+W dependent
+// multiply-adds, ~7 us of pure latency) runs in registers with its W+1 saved words in LDS ([word][thread], row stride
+// 65: conflict-free).  No queue, no atomics: a single hot counter serialised the ~7 000 appends per step in L2.
+#define REFILL_BS 64
+__global__ __launch_bounds__(REFILL_BS) void k_mt_refill(u32 *rng, int N, u32 W)
+{
+    extern __shared__ u32 sm[]; // (W + 1) rows of 65 words
+    const int t = threadIdx.x, lane = blockIdx.x * REFILL_BS + t;
+    uint4 h = make_uint4(0u, 0u, 0u, 0u);
+    if (lane < N) h = *rng_hdr_ptr(rng, lane);
+    const bool act = (h.w & RNGF_NEED) != 0;
+    if (!__any(act)) return;
+    if (!act) return;
+    u32 s = h.z; // the NEXT episode's seed
+    for (u32 i = 0; i <= W; i++) { sm[i * 65 + t] = s; s = 1812433253u * (s ^ (s >> 30)) + i + 1u; }  // s[0..W]
+    for (u32 i = W + 1; i < 397; i++) s = 1812433253u * (s ^ (s >> 30)) + i + 1u;                       // -> s[397]
+    u32 *dst = rng_win_ptr(rng, N, W, lane, h.w ^ RNGF_SLOT);
+    u32 a = sm[t];
+    #pragma unroll 8
+    for (u32 n = 0; n < W; n++) {   // output n = temper(s[397+n] ^ twist(s[n], s[n+1]))
+        const u32 b = sm[(n + 1) * 65 + t];
+        dst[n] = mt_temper(s ^ mt_twist(a, b));
+        s = 1812433253u * (s ^ (s >> 30)) + (397u + n) + 1u;
+        a = b;
+    }
+    rng_hdr_ptr(rng, lane)->w = (h.w & ~RNGF_NEED) | RNGF_SPARE;
 }
 
 struct StepRes { double reward; int term, trunc, info; };
@@ -179,7 +223,7 @@ __global__ __launch_bounds__(BS) void k_reset(Geom g, KCfg c, KState st, const u
         uint4 *hp = rng_hdr_ptr(st.rng, lane);
         const u32 seed = seeds ? seeds[lane] : hp->z;
         GState<NW> s; int dice; LaneRng r;
-        lane_reset<NW>(g, c, seed, rng_win_ptr(st.rng, c.N, c.W, lane), s, dice, r);
+        lane_reset<NW>(g, c, st.rng, lane, seed, s, dice, r);
         *hp = r.header();
         st.dice[lane] = (int8_t)dice;
         st.done[lane] = 0;
@@ -252,8 +296,8 @@ __global__ __launch_bounds__(BS) void k_step(Geom g, KCfg c, KState st, const in
                 if (out.tboard) for (int i = 0; i < g.cells; i++) mine_t[i] = mine[i];
                 if (out.tdice) out.tdice[lane] = (int8_t)dice;
             } else {
-                u32 *win = rng_win_ptr(st.rng, c.N, c.W, lane);
-                LaneRng r; r.load(c.rng_kind, hdr, win, c.W, c.key);
+                LaneRng r; r.load(c.rng_kind, hdr, rng_win_ptr(st.rng, c.N, c.W, lane, hdr.w), c.W, c.key);
+                r.prefetch();
                 if (PHASE != 2) r.begin_step();
                 GState<NW> s;
                 decode_board<NW>(g, mine, s);
@@ -285,7 +329,7 @@ __global__ __launch_bounds__(BS) void k_step(Geom g, KCfg c, KState st, const in
                     if (out.tdice) out.tdice[lane] = (int8_t)dice;
                     if (o.term) {
                         if (c.autoreset) {
-                            lane_reset<NW>(g, c, r.next_seed, win, s, dice, r);
+                            lane_auto_reset<NW>(g, c, st.rng, lane, sc, s, dice, r);
                             if (c.shaped && c.refresh && st.prev_score) st.prev_score[lane] = evaluate<NW>(g, s, EWN_H_HYBRID);
                         } else st.done[lane] = 1;
                     }
@@ -556,7 +600,7 @@ static int check_cfg(const ewn_config *cfg, Geom &g, KCfg &k)
     k.rng_kind = cfg->rng_kind; k.shaped = cfg->shaped; k.autoreset = cfg->autoreset; k.refresh = cfg->shaped_refresh_on_reset;
     k.lane_offset = cfg->lane_offset; k.nsim_total = cfg->num_simulations * cfg->num_env_copies;
     k.seed_stride = cfg->seed_stride; k.W = W;
-    k.rng_words = EWN_RNG_HDR + (cfg->rng_kind == EWN_RNG_MT19937 ? W : 0u);
+    k.rng_words = EWN_RNG_HDR + (cfg->rng_kind == EWN_RNG_MT19937 ? 2u * W : 0u);
     k.reward = cfg->reward; k.illegal_reward = cfg->illegal_move_reward; k.key = cfg->philox_key;
     return EWN_OK;
 }
@@ -740,6 +784,12 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
     KState ks = kstate(st);
     if (!cfg->shaped) { ks.prev_score = nullptr; ks.tolerance = nullptr; }
     KScratch sc = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    // MT kind with auto-reset: the step kernel flags the lanes whose spare window it consumed; k_mt_refill rebuilds them right after
+    const bool refill = cfg->rng_kind == EWN_RNG_MT19937 && cfg->autoreset;
+    if (cfg->opponent_kind == EWN_OPP_MCTS) {
+        if (!scratch) return EWN_ENULL;
+        carve_scratch(g, k, scratch, sc);
+    }
     const size_t lds = (size_t)2 * BS * g.cells;
     if (cfg->opponent_kind != EWN_OPP_MCTS) {
         const bool fast = st->tables && fast_tables_bytes(g.S, g.L) > 0 && cfg->opponent_kind == EWN_OPP_MINIMAX &&
@@ -754,7 +804,8 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
             const int gpb = D3_BS / T;
             const dim3 grid((unsigned)((k.N + gpb - 1) / gpb));
             const size_t l3 = (((size_t)2 * gpb * g.cells + 15) & ~(size_t)15);
-#define D3_LAUNCH(SS, TT, OO) k_step_d3<SS, TT, OO><<<grid, D3_BS, l3 + FAST_TAB_BYTES(SS), s>>>(dc, db)
+#define D3_LAUNCH(SS, TT, OO) do { if (k.rng_kind == 0) k_step_d3<SS, TT, OO, 0><<<grid, D3_BS, l3 + FAST_TAB_BYTES(SS), s>>>(dc, db); \
+                                   else k_step_d3<SS, TT, OO, 1><<<grid, D3_BS, l3 + FAST_TAB_BYTES(SS), s>>>(dc, db); } while (0)
 #define D3_BY_T(SS) do { if (lean_random) D3_LAUNCH(SS, 1, 1); else if (T == 1) D3_LAUNCH(SS, 1, 0); else if (T == 2) D3_LAUNCH(SS, 2, 0); else D3_LAUNCH(SS, 4, 0); } while (0)
             switch (g.S) {
             case 5: D3_BY_T(5); break;
@@ -762,9 +813,7 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
             case 7: D3_BY_T(7); break;
             default: D3_BY_T(8); break;
             }
-            return launch_status();
-        }
-        if (fast) {
+        } else if (fast) {
             const size_t base = (lds + 15) & ~(size_t)15;
             switch (g.S) {
             case 5: k_step<1, 0, 5><<<GRID(k.N), BS, base + FAST_TAB_BYTES(5), s>>>(g, k, ks, actions, ko, sc); break;
@@ -772,23 +821,27 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
             case 7: k_step<1, 0, 7><<<GRID(k.N), BS, base + FAST_TAB_BYTES(7), s>>>(g, k, ks, actions, ko, sc); break;
             default: k_step<1, 0, 8><<<GRID(k.N), BS, base + FAST_TAB_BYTES(8), s>>>(g, k, ks, actions, ko, sc); break;
             }
-            return launch_status();
+        } else {
+            BY_NW(g, (k_step<1, 0, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)),
+                  (k_step<2, 0, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)));
         }
-        BY_NW(g, (k_step<1, 0, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)),
-              (k_step<2, 0, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)));
-        return launch_status();
+    } else {
+        BY_NW(g, (k_step<1, 1, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)),
+              (k_step<2, 1, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)));
+        rc = launch_status();
+        if (rc) return rc;
+        rc = mcts_launch(g, k.N, sc.cboard, sc.cdice, sc.phase, k.nsim_total, k.key, sc.obs_id, sc.act, sc.wins, s);
+        if (rc) return rc;
+        BY_NW(g, (k_step<1, 2, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)),
+              (k_step<2, 2, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)));
     }
-    if (!scratch) return EWN_ENULL;
-    carve_scratch(g, k, scratch, sc);
-    BY_NW(g, (k_step<1, 1, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)),
-          (k_step<2, 1, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)));
     rc = launch_status();
     if (rc) return rc;
-    rc = mcts_launch(g, k.N, sc.cboard, sc.cdice, sc.phase, k.nsim_total, k.key, sc.obs_id, sc.act, sc.wins, s);
-    if (rc) return rc;
-    BY_NW(g, (k_step<1, 2, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)),
-          (k_step<2, 2, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)));
-    return launch_status();
+    if (refill) {
+        k_mt_refill<<<dim3((unsigned)((k.N + REFILL_BS - 1) / REFILL_BS)), REFILL_BS, (size_t)(k.W + 1) * 65 * 4, s>>>(st->rng, k.N, k.W);
+        rc = launch_status();
+    }
+    return rc;
 }
 
 static int query_geom(int S, int L, int M, const void *boards, Geom &g)

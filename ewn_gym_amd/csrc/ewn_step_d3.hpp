@@ -322,21 +322,11 @@ EWN_DEV void d3_init_state(const FastTab<S> *Tb, RState<S> &s)
     s.P = (M)Tb->init_P; s.N = (M)Tb->init_N; s.posP = Tb->init_posP; s.posN = Tb->init_posN; s.aliveP = s.aliveN = 63u;
 }
 
-// reset(seed) + setup_game (envs/ewn.py:488-494, 94-108)
-template <int S>
-EWN_DEV void d3_reset(const FastTab<S> *Tb, const D3Cfg &c, u32 seed, u32 *win, RState<S> &s, int &dice, LaneRng &r)
-{
-    // all T lanes of the group fill the window with identical values (each lane only ever reads back its own stores)
-    if (c.rng_kind == 0) mt_fill_window(seed, (int)c.W, win);
-    r.load(c.rng_kind, make_uint4(seed, 0u, seed + c.seed_stride, 0u), win, c.W, c.key);
-    d3_init_state<S>(Tb, s);
-    dice = r.first_dice(6);
-}
-
 // EinsteinWuerfeltNichtEnv.step (envs/ewn.py:436-486), minimax(depth 3, hybrid) opponent, cube_layer 3.
 // T lanes per game; lanes of a group run identical code on identical data except inside d3_search.
 // OPP 0: ExpectiMinimaxAgent(max_depth=3, 'hybrid') reply;  OPP 1: RandomAgent reply (classical_policies/random_policy.py:11-15)
-template <int S, int T, int OPP>
+// RNGK: the dice RNG kind as a compile-time constant, so each instantiation carries only its own generator's registers
+template <int S, int T, int OPP, int RNGK>
 __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
 {
     constexpr int CELLS = S * S, GPB = D3_BS / T; // games per block
@@ -367,8 +357,8 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
     double reward = 0.0;
     int term = 0, trunc = 0, info = EWN_INFO_NONE;
     RState<S> s;
-    u32 *win = rng_win_ptr(B.rng, c.N, c.W, live ? game : 0);
-    LaneRng r; r.load(c.rng_kind, hdr, win, c.W, c.key);
+    LaneRng r; r.load(RNGK, hdr, rng_win_ptr(B.rng, c.N, c.W, live ? game : 0, hdr.w), c.W, c.key);
+    r.prefetch();
     r.begin_step();
     d3_decode<S, T>(live ? mine : lds, sub, s); // every lane takes part (DPP combine); non-live lanes read game 0 of the block
     const bool active = live && !frozen;
@@ -421,7 +411,11 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
     if (live && writer && B.tdice) B.tdice[game] = (int8_t)dice;
     if (active) {
         if (term) {
-            if (c.autoreset) d3_reset<S>(Tb, c, r.next_seed, win, s, dice, r);
+            if (c.autoreset) { // reset(seed = next_seed) + setup_game (envs/ewn.py:488-494, 94-108)
+                r.next_episode(B.rng, c.N, game, c.seed_stride, c.key);
+                d3_init_state<S>(Tb, s);
+                dice = r.first_dice(6);
+            }
             else if (writer) B.done[game] = 1;
         }
         d3_encode<S, T>(Tb, s, sub, mine);
