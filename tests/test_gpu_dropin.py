@@ -147,3 +147,35 @@ def test_ansi_render(capsys):
     env.render()
     out = capsys.readouterr().out
     assert out.startswith("dice:\n5\nboard:\n")
+
+
+def test_sb3_vec_env_adapter_contract():
+    """The VecEnv surface SB3's A2C drives (reset -> dict of numpy, step -> obs, rewards, dones, infos with
+    terminal_observation on auto-reset); checked against the single-game drop-in env on the same seeds."""
+    import envs
+    import ewn_gym_amd as ea
+    from ewn_gym_amd.sb3_adapter import EWNVecEnv
+    N = 64
+    ve = EWNVecEnv(ea.VecEWN(N, opponent_policy="random", rng="mt19937", autoreset=True, want_terminal_obs=True, seed_stride=1000))
+    ve.seed(100)
+    obs = ve.reset()
+    assert obs["board"].shape == (N, 5, 5) and obs["board"].dtype == np.int16 and obs["dice_roll"].dtype == np.int64
+    single = envs.EinsteinWuerfeltNichtEnv()
+    o1, _ = single.reset(seed=103)
+    assert np.array_equal(o1["board"], obs["board"][3]) and o1["dice_roll"] == obs["dice_roll"][3]
+    seen_terminal = 0
+    for t in range(30):
+        acts = np.stack([np.zeros(N, np.int64), np.full(N, t % 3)], 1)
+        before = obs
+        obs, rewards, dones, infos = ve.step(acts)
+        assert rewards.dtype == np.float32 and dones.dtype == bool and len(infos) == N
+        for i in np.nonzero(dones)[0]:
+            assert "terminal_observation" in infos[i] and infos[i]["TimeLimit.truncated"] is False
+            assert infos[i]["terminal_observation"]["board"].shape == (5, 5)
+            assert np.array_equal(obs["board"][i], before["board"][i] * 0 + single.reset(seed=0)[0]["board"])  # fresh episode
+            seen_terminal += 1
+        for i in np.nonzero(~dones)[0]:
+            assert "terminal_observation" not in infos[i]
+    assert seen_terminal > N
+    with pytest.raises(ea.EwnError):
+        EWNVecEnv(ea.VecEWN(4))
