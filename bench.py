@@ -161,19 +161,26 @@ def main():
         roof = None
         if kms is not None:
             achieved = N * bytes_per / (kms * 1e-3) / 1e9
-            traffic = None
+            traffic = valu = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get("%s_d%d_%s" % (args.opponent, args.max_depth, args.rng))
+            if os.path.exists(tpath) and N == 65536 and args.board_size == 5:
+                try:   # PMC results of this kernel at this size, collected by tools_pmc.sh in separate rocprofv3 passes
+                    pmc = json.load(open(tpath))
+                    key = "%s_d%d_%s" % (args.opponent, args.max_depth, args.rng)
+                    traffic = pmc.get(key)
+                    vi = pmc.get(key + "_valu_wave_insts")
+                    if vi:   # the bound that actually binds: integer VALU issue, one wave-instruction per 4 cycles per SIMD
+                        peak = 1024 * 2.4e9 / 4
+                        valu = {"wave_insts_per_launch": vi, "achieved_per_s": vi / (kms * 1e-3), "peak_per_s": peak,
+                                "frac": vi / (kms * 1e-3) / peak, "unit": "VALU wave-instructions/s (256 CUs x 4 SIMDs, 2.4 GHz, 4 cycles each)"}
                 except Exception:
-                    traffic = None
+                    traffic = valu = None
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "kernel": "k_step (fused agent move + opponent search + reply + auto-reset)",
+                    "traffic": traffic, "valu_issue": valu, "kernel": "k_step (fused agent move + opponent search + reply + auto-reset)",
                     "kernel_ms": kms, "algorithmic_bytes_per_launch": N * bytes_per,
                     "note": "integer/fp64-compare search work: VALU-bound, far from the HBM roof by construction (SURVEY 8d)"}
         cpub = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only
             cpub = cpu_baseline(args, args.cpu_baseline_seconds)
         line = {
             "metric": "env steps/sec (whole node), 5x5 EWN, depth-3 expectiminimax opponent" if
@@ -181,7 +188,7 @@ def main():
                       "env steps/sec (whole node), %dx%d EWN, %s opponent" % (args.board_size, args.board_size, args.opponent),
             "value": value, "unit": "env steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8 boards / u64 bitboards / f64 heuristic", "data": "synthetic",
+            "dtype": "u32 bitboards (int8 boards in HBM), f64 expectation", "data": "synthetic",
             "config": {"workload": "%dx%d EWN, %d parallel envs per GPU, %s opponent%s, random-legal agent, auto-reset, %s dice RNG"
                                    % (args.board_size, args.board_size, N, args.opponent,
                                       " depth %d (hybrid heuristic)" % args.max_depth if args.opponent == "minimax" else "", args.rng),

@@ -6,6 +6,6 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 tag=$1; shift
 mkdir -p $R/gpurun_out/pmc_$tag
 cd /tmp && export TMPDIR=/tmp
-for c in FETCH_SIZE WRITE_SIZE; do
+for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_$tag -o $c -- python3 $R/bench.py "$@" --no-cpu-baseline > $R/gpurun_out/pmc_$tag/$c.json 2> $R/gpurun_out/pmc_$tag/$c.err
 done
