@@ -62,8 +62,17 @@ def load():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise EwnError("libewn_hip.so not found at %s: build it with `python -m ewn_gym_amd.build` "
-                       "(there is no CPU fallback)" % LIB_PATH)
+        built = False
+        if "EWN_HIP_LIB" not in os.environ:
+            try:  # a fresh checkout: compile in-tree once (hipcc cross-compiles gfx950 without a GPU)
+                from . import build as _build
+                _build.build()
+                built = os.path.exists(LIB_PATH)
+            except Exception:
+                built = False
+        if not built:
+            raise EwnError("libewn_hip.so not found at %s and could not be built: run `python -m ewn_gym_amd.build` "
+                           "(there is no CPU fallback)" % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     vp, i32, u32, u64 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64
     cfgp, stp, outp = C.POINTER(EwnConfig), C.POINTER(EwnState), C.POINTER(EwnStepOut)
