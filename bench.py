@@ -2,9 +2,11 @@
 """bench.py -- env steps/sec of the vectorised EWN step + depth-3 expectiminimax opponent.
 
 One "step" = one pass of the hot path over one batch: a device-side stand-in agent
-samples a uniformly random LEGAL action per lane (ewn_predict_random), then ewn_step
-applies it, rolls the opponent's dice, runs the opponent's search/reply, tests for the
-win, rolls the next dice and auto-resets finished lanes -- for every lane.
+plays a uniformly random LEGAL action per lane (RandomAgent; by default emitted by the step
+kernel itself for the new observation, or by a separate policy kernel with
+--separate-agent-kernel), and ewn_step applies it, rolls the opponent's dice, runs the
+opponent's search/reply, tests for the win, rolls the next dice and auto-resets finished
+lanes -- for every lane.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--lanes 65536] [--opponent minimax] ...
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -42,6 +44,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the N>1 path on one GPU)")
+    ap.add_argument("--separate-agent-kernel", action="store_true",
+                    help="sample the agent's action with a separate policy kernel (ewn_predict_random) instead of ewn_step's fused "
+                         "random_action output")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly from Python instead of replaying a hipGraph")
     ap.add_argument("--graph-steps", type=int, default=50, help="steps captured per graph")
     return ap.parse_args()
@@ -96,17 +101,26 @@ def main():
     lo, hi = lane_range(N * world, world, rank)  # weak scaling: every GPU owns N lanes, global ids [rank*N, (rank+1)*N)
     env = ea.VecEWN(N, board_size=args.board_size, cube_layer=args.cube_layer, opponent_policy=args.opponent,
                     max_depth=args.max_depth, rng=args.rng, autoreset=True, lane_offset=lo, seed_stride=N * world,
-                    philox_key=2024, num_simulations=args.num_simulations, num_env_copies=args.num_env_copies)
+                    philox_key=2024, num_simulations=args.num_simulations, num_env_copies=args.num_env_copies,
+                    want_random_action=not args.separate_agent_kernel)
     from ewn_gym_amd.sharding import lane_seeds
     env.reset(seeds=lane_seeds(lo, hi).cuda())  # reference default seed 9487 + global lane id
-    actions = torch.zeros((N, 2), dtype=torch.int8, device="cuda")
-
     counter = torch.zeros((), dtype=torch.int32, device="cuda")  # device-side step index: lets the captured graph advance
+    fused_agent = not args.separate_agent_kernel
+    if fused_agent:
+        # The stand-in agent is RandomAgent: ewn_step itself emits RandomAgent.predict(new observation) into
+        # ewn_step_out.random_action, and that buffer is the next step's `actions` (one kernel per step).
+        actions = env.random_action
+        env.sample_legal_actions(0, out=actions)      # the very first action
+    else:
+        actions = torch.zeros((N, 2), dtype=torch.int8, device="cuda")
 
     def one_step():
-        env.sample_legal_actions(0, out=actions, step_tensor=counter)   # the stand-in agent (RandomAgent as a device policy)
-        env.step(actions)                                               # the hot path
-        counter.add_(1)
+        if not fused_agent:
+            env.sample_legal_actions(0, out=actions, step_tensor=counter)   # RandomAgent as a separate device policy kernel
+        env.step(actions)                                                   # the hot path
+        if not fused_agent:
+            counter.add_(1)
 
     def barrier():
         if world > 1:
@@ -146,11 +160,13 @@ def main():
     if not args.no_kernel_timing:
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
         for k in range(args.steps):
-            env.sample_legal_actions(0, out=actions, step_tensor=counter)
+            if not fused_agent:
+                env.sample_legal_actions(0, out=actions, step_tensor=counter)
             ev[k][0].record()
             env.step(actions)
             ev[k][1].record()
-            counter.add_(1)
+            if not fused_agent:
+                counter.add_(1)
         torch.cuda.synchronize()
         kms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
 
@@ -189,7 +205,8 @@ def main():
             "value": value, "unit": "env steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 bitboards (int8 boards in HBM), f64 expectation", "data": "synthetic",
-            "config": {"workload": "%dx%d EWN, %d parallel envs per GPU, %s opponent%s, random-legal agent, auto-reset, %s dice RNG"
+            "config": {"workload": ("%%dx%%d EWN, %%d parallel envs per GPU, %%s opponent%%s, random-legal agent (%s), auto-reset, %%s dice RNG"
+                                    % ("emitted by the step kernel" if fused_agent else "separate policy kernel"))
                                    % (args.board_size, args.board_size, N, args.opponent,
                                       " depth %d (hybrid heuristic)" % args.max_depth if args.opponent == "minimax" else "", args.rng),
                        "lanes_per_gpu": N, "board_size": args.board_size, "cube_layer": args.cube_layer,

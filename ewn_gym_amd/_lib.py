@@ -46,7 +46,7 @@ class EwnState(C.Structure):  # struct ewn_state
 
 class EwnStepOut(C.Structure):  # struct ewn_step_out
     _fields_ = [("reward", C.c_void_p), ("terminated", C.c_void_p), ("truncated", C.c_void_p), ("info", C.c_void_p),
-                ("terminal_board", C.c_void_p), ("terminal_dice", C.c_void_p)]
+                ("terminal_board", C.c_void_p), ("terminal_dice", C.c_void_p), ("random_action", C.c_void_p)]
 
 
 class EwnError(RuntimeError):

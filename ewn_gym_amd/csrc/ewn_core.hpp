@@ -391,6 +391,19 @@ EWN_DEV u32 fmix32(u32 h) // MurmurHash3 finaliser
     return h;
 }
 
+// The fused stand-in agent's randomness (ewn_step_out.random_action): one 32-bit hash per (episode, draws so far, lane)
+EWN_DEV u32 agent_hash(u32 seed, u32 draws, u32 lane_global, u64 key)
+{
+    return fmix32(seed ^ fmix32(draws * 0x9E3779B1u + lane_global) ^ fmix32((u32)key ^ 0x41474E54u) ^ ((u32)(key >> 32) * 0x85ebca6bu));
+}
+
+// k-th (0-based) set bit of a 6-bit legal mask (bits 0-2: first cube's dirs, 3-5: second cube's) -> slot index
+EWN_DEV int nth_set_bit(u32 m, int k)
+{
+    for (int i = 0; i < k; i++) m &= m - 1;
+    return __ffs((int)m) - 1;
+}
+
 // One lane's dice stream for the duration of a kernel.
 //  kind 0 (MT19937): np.random.seed / legacy randint, bit-exact with the reference.
 //  kind 1 (Philox):  word n of an episode = philox4x32-10(ctr={n>>2, seed, 0, 'ENV1'}, key)[n&3].  A step starts on a

@@ -25,7 +25,7 @@ struct KState {
 };
 
 struct KOut {
-    double *reward; uint8_t *terminated; uint8_t *truncated; uint8_t *info; int8_t *tboard; int8_t *tdice;
+    double *reward; uint8_t *terminated; uint8_t *truncated; uint8_t *info; int8_t *tboard; int8_t *tdice; int8_t *ract;
 };
 
 struct KScratch { // split-phase step (MCTS opponent)
@@ -295,6 +295,7 @@ __global__ __launch_bounds__(BS) void k_step(Geom g, KCfg c, KState st, const in
                 if (PHASE == 1) sc.phase[lane] = 0;
                 if (out.tboard) for (int i = 0; i < g.cells; i++) mine_t[i] = mine[i];
                 if (out.tdice) out.tdice[lane] = (int8_t)dice;
+                if (out.ract) ((uint16_t *)out.ract)[lane] = 0;
             } else {
                 LaneRng r; r.load(c.rng_kind, hdr, rng_win_ptr(st.rng, c.N, c.W, lane, hdr.w), c.W, c.key);
                 r.prefetch();
@@ -337,6 +338,18 @@ __global__ __launch_bounds__(BS) void k_step(Geom g, KCfg c, KState st, const in
                 *rng_hdr_ptr(st.rng, lane) = r.header();
                 encode_board<NW>(g, s, mine);
                 st.dice[lane] = (int8_t)dice;
+                if (settled && out.ract) { // RandomAgent.predict on the post-step observation
+                    int f = 0, d = 0;
+                    if (!(o.term && !c.autoreset)) {
+                        const int n = for_each_legal<0, NW>(g, s, dice, [](int, int, int) { return true; });
+                        if (n > 0) {
+                            const int pick = (int)__umulhi(agent_hash(r.seed, r.draws(), (u32)(c.lane_offset + lane), c.key), (u32)n);
+                            int i = 0;
+                            for_each_legal<0, NW>(g, s, dice, [&](int flag, int, int dir) { if (i == pick) { f = flag; d = dir; } i++; return i <= pick; });
+                        }
+                    }
+                    ((uint16_t *)out.ract)[lane] = (uint16_t)((uint8_t)f | ((uint16_t)(uint8_t)d << 8));
+                }
             }
             if (settled) {
                 out.reward[lane] = o.reward; out.terminated[lane] = (uint8_t)o.term;
@@ -811,7 +824,7 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
     if (!out->reward || !out->terminated || !out->truncated || !out->info) return EWN_ENULL;
     if (cfg->shaped && (!st->prev_score || !st->tolerance)) return EWN_ENULL;
     hipStream_t s = (hipStream_t)stream;
-    KOut ko = { out->reward, out->terminated, out->truncated, out->info, out->terminal_board, out->terminal_dice };
+    KOut ko = { out->reward, out->terminated, out->truncated, out->info, out->terminal_board, out->terminal_dice, out->random_action };
     KState ks = kstate(st);
     if (!cfg->shaped) { ks.prev_score = nullptr; ks.tolerance = nullptr; }
     KScratch sc = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
@@ -829,9 +842,9 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
         if ((fast || lean_random) && !cfg->shaped && d3_threads_per_game(k.N) > 0) {
             // the lean fused kernel: canonical ring space end to end, T lanes per game (ewn_step_d3.hpp)
             const int T = lean_random ? 1 : d3_threads_per_game(k.N);
-            D3Cfg dc = { k.N, k.rng_kind, k.autoreset, k.seed_stride, k.W, k.reward, k.key };
+            D3Cfg dc = { k.N, k.rng_kind, k.autoreset, k.lane_offset, k.seed_stride, k.W, k.reward, k.key };
             D3Buf db = { st->board, st->dice, st->done, st->rng, st->tables, actions, out->reward, out->terminated,
-                         out->truncated, out->info, out->terminal_board, out->terminal_dice };
+                         out->truncated, out->info, out->terminal_board, out->terminal_dice, out->random_action };
             const int gpb = D3_BS / T;
             const dim3 grid((unsigned)((k.N + gpb - 1) / gpb));
             const size_t l3 = (((size_t)2 * gpb * g.cells + 15) & ~(size_t)15);

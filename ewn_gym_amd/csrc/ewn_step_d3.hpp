@@ -243,7 +243,7 @@ __device__ __forceinline__ double fast_d3(const FastTab<S> *Tb, const GState<1> 
 // ---------------------------------------------------------------- the fused step kernel
 
 struct D3Cfg {
-    int N, rng_kind, autoreset;
+    int N, rng_kind, autoreset, lane_offset;
     u32 seed_stride, W;
     double reward;
     u64 key;
@@ -251,7 +251,7 @@ struct D3Cfg {
 
 struct D3Buf {
     int8_t *board; int8_t *dice; uint8_t *done; u32 *rng; const void *tables; const int8_t *actions;
-    double *reward; uint8_t *terminated; uint8_t *truncated; uint8_t *info; int8_t *tboard; int8_t *tdice;
+    double *reward; uint8_t *terminated; uint8_t *truncated; uint8_t *info; int8_t *tboard; int8_t *tdice; int8_t *ract;
 };
 
 #define D3_BS 256
@@ -423,6 +423,29 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
             *rng_hdr_ptr(B.rng, game) = r.header();
             B.dice[game] = (int8_t)dice;
         }
+    }
+    if (live && writer && B.ract) {
+        // RandomAgent.predict on the post-step observation (the agent is the canonical BOTTOM_RIGHT side)
+        int f = 0, d = 0;
+        if (!(frozen || (term && !c.autoreset))) {
+            const CubeSel cs = select_cubes(s.aliveN, dice);
+            const bool have0 = cs.exact || cs.has_up, have1 = !cs.exact && cs.has_down;
+            const int p0 = pk_get(s.posN, have0 ? (cs.exact ? cs.k_exact : cs.k_up) : 0), p1 = pk_get(s.posN, have1 ? cs.k_down : 0);
+            u32 okm = 0;
+            #pragma unroll
+            for (int dd = 0; dd < 3; dd++) {
+                okm |= ((have0 && Tb->nbn[dd][p0] != 255) ? 1u : 0u) << dd;
+                okm |= ((have1 && Tb->nbn[dd][p1] != 255) ? 1u : 0u) << (3 + dd);
+            }
+            const int n = __popc(okm);
+            if (n > 0) {
+                const u32 w = agent_hash(r.seed, r.draws(), (u32)(c.lane_offset + game), c.key);
+                const int slot = nth_set_bit(okm, (int)__umulhi(w, (u32)n));
+                f = slot < 3 ? (cs.exact ? 0 : 1) : 0;
+                d = slot < 3 ? slot : slot - 3;
+            }
+        }
+        ((uint16_t *)B.ract)[game] = (uint16_t)((uint8_t)f | ((uint16_t)(uint8_t)d << 8));
     }
     if (live && writer) {
         B.reward[game] = reward; B.terminated[game] = (uint8_t)term;

@@ -52,7 +52,7 @@ class VecEWN:
                  num_simulations=10, num_env_copies=5, rng="mt19937", shaped=False, reward=1.0,
                  illegal_move_reward=-1.0, illegal_move_tolerance=10, autoreset=False, shaped_refresh_on_reset=False,
                  lane_offset=0, seed_stride=None, philox_key=0, mt_window=0, want_terminal_obs=False, device="cuda",
-                 use_tables=True):
+                 use_tables=True, want_random_action=False):
         self.lib = _lib.load()
         opp = str(opponent_policy)
         if opp not in OPP:
@@ -81,6 +81,8 @@ class VecEWN:
         self.info = torch.zeros(N, dtype=torch.uint8, device=dev)
         self.terminal_board = torch.zeros((N, S, S), dtype=torch.int8, device=dev) if want_terminal_obs else None
         self.terminal_dice = torch.zeros(N, dtype=torch.int8, device=dev) if want_terminal_obs else None
+        # RandomAgent.predict on the post-step observation, fused into ewn_step (ewn_step_out.random_action)
+        self.random_action = torch.zeros((N, 2), dtype=torch.int8, device=dev) if want_random_action else None
         nscr = check(self.lib.ewn_step_scratch_bytes(C.byref(self.cfg)), "ewn_step_scratch_bytes")
         self.scratch = torch.zeros(max(int(nscr), 8), dtype=torch.uint8, device=dev)
         self._actions = torch.zeros((N, 2), dtype=torch.int8, device=dev)
@@ -88,7 +90,7 @@ class VecEWN:
         self._st = EwnState(_ptr(self.board), _ptr(self.dice), _ptr(self.done), _ptr(self.rng_state),
                             _ptr(self.prev_score), _ptr(self.tolerance), _ptr(self.tables))
         self._out = EwnStepOut(_ptr(self.reward), _ptr(self.terminated), _ptr(self.truncated), _ptr(self.info),
-                               _ptr(self.terminal_board), _ptr(self.terminal_dice))
+                               _ptr(self.terminal_board), _ptr(self.terminal_dice), _ptr(self.random_action))
         check(self.lib.ewn_init_aux(C.byref(self.cfg), C.byref(self._st), _stream()), "ewn_init_aux")
 
     # -- reset(seed) for the lanes selected by mask (envs/ewn.py:488-494)

@@ -120,6 +120,10 @@ typedef struct ewn_step_out {
     uint8_t *info;         /* [N] EWN_INFO_* */
     int8_t *terminal_board;/* [N][S*S] observation before auto-reset (SB3 "terminal_observation"); NULL to skip */
     int8_t *terminal_dice; /* [N] ; NULL to skip */
+    int8_t *random_action; /* [N][2] ; NULL to skip.  RandomAgent.predict (classical_policies/random_policy.py:11-15) on the
+                              POST-step observation, fused into the step: a uniformly random legal action of the agent,
+                              drawn from a hash of (episode seed, draws so far, global lane id, philox_key).  May alias
+                              `actions` (each lane reads its action before it writes the next one). */
 } ewn_step_out;
 
 int ewn_abi_version(void);

@@ -194,6 +194,11 @@ class OracleVecEnv:
         out = (b, d, r, te, tr, info)
         return out + (tb, td) if want_terminal else out
 
+    def random_actions(self):
+        a = np.zeros((self.N, 2), np.int8)
+        lib().ewn_oracle_random_actions(C.c_void_p(self.h), _p(a))
+        return a
+
     def sample_legal_actions(self, step):
         a = np.zeros((self.N, 2), np.int8)
         lib().ewn_oracle_sample_legal_actions(C.c_void_p(self.h), C.c_uint32(step), _p(a))

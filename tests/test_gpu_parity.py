@@ -240,6 +240,39 @@ def test_mt_window_overflow_closed_form(ea):
     _lockstep(ea, 300, 60, board_size=7, cube_layer=5, rng="mt19937", mt_window=16)
 
 
+@pytest.mark.parametrize("kw", [dict(opponent_policy="minimax", max_depth=3, rng="philox"),
+                                dict(opponent_policy="random", rng="mt19937"),
+                                dict(opponent_policy="minimax", max_depth=2, rng="philox", board_size=7),
+                                dict(opponent_policy="minimax", max_depth=3, rng="mt19937", use_tables=False)])
+def test_fused_random_agent_output(ea, kw):
+    """ewn_step_out.random_action: RandomAgent.predict on the post-step observation, fused into the step kernel and
+    fed back as the next action (the buffer aliases `actions`), lock-step against the oracle's restatement."""
+    N = 1536
+    okw = dict(kw)
+    opp = okw.pop("opponent_policy")
+    okw.pop("use_tables", None)
+    env = ea.VecEWN(N, autoreset=True, want_random_action=True, lane_offset=77, philox_key=99, **kw)
+    orc = po.OracleVecEnv(N, opponent=opp, autoreset=True, lane_offset=77, philox_key=99, **okw)
+    seeds = np.arange(N, dtype=np.uint32) + 31
+    env.reset(seeds=seeds)
+    orc.reset(seeds=seeds)
+    acts = orc.random_actions()
+    buf = env.random_action
+    buf.copy_(torch.from_numpy(acts))
+    S = kw.get("board_size", 5)
+    for t in range(25):
+        res = [cpu(x) for x in env.step(buf)]     # reads buf, writes the next random legal action into buf
+        ores = orc.step(acts)
+        for a, o in zip(res, ores):
+            assert np.array_equal(a, o), t
+        acts = orc.random_actions()
+        got = cpu(buf)
+        assert np.array_equal(got, acts), (t, np.nonzero((got != acts).any(1))[0][:5])
+        la, n, _, _, _ = po.legal_actions(ores[0], ores[1], player=1)
+        ok = ((la[:, :, 0] == acts[:, None, 0]) & (la[:, :, 1] == acts[:, None, 1])).any(1)
+        assert ok.all()
+
+
 def test_frozen_lanes_without_autoreset(ea):
     N = 512
     env = ea.VecEWN(N, rng="mt19937")
