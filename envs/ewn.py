@@ -147,6 +147,33 @@ class EinsteinWuerfeltNichtEnv(_Base):
         assert num != 0
         return num - 1 if player == Player.TOP_LEFT else -num    # python-style index into cube_pos, :185-186
 
+    def _push_board(self):
+        self._engine.set_obs(self.board.astype(np.int8)[None], [self.dice_roll])
+
+    def make_simulated_action(self, player: Player, action):
+        """envs/ewn.py:377-412: apply [flag, dir] for `player` on the host-visible board, remembering how to undo it.
+        An illegal move pushes None, like upstream."""
+        import ewn_gym_amd
+        a = np.asarray(action).reshape(-1)
+        nb, valid = ewn_gym_amd.apply_action(self.board.astype(np.int8)[None], [self.dice_roll], [[int(a[0]), int(a[1])]],
+                                             player=player.value, cube_layer=self.cube_layer)
+        if not bool(valid[0].item()):
+            self.history.append(None)
+            return
+        self.history.append(self.board.copy())
+        self.board[:] = nb[0].cpu().numpy()
+        self._push_board()
+
+    def undo_simulated_action(self):
+        """envs/ewn.py:414-434"""
+        if not self.history:
+            return
+        last = self.history.pop()
+        if last is None:
+            return
+        self.board[:] = last
+        self._push_board()
+
     @property
     def cube_pos(self):
         """The reference's masked structured array of cube coordinates (envs/ewn.py:57), rebuilt from the board."""

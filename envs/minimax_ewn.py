@@ -25,10 +25,21 @@ class MinimaxEnv(EinsteinWuerfeltNichtEnv):
         self.dice_roll = roll
         self._engine.dice[0] = int(roll)
 
+    def simulate(self) -> float:
+        """envs/minimax_ewn.py:215-238: fraction of num_simulations random playouts TOP_LEFT wins; the player who is NOT
+        `current_player` moves first (upstream switches before every move), and -- upstream quirk -- current_player is
+        left wherever the last playout ended; here it is simply left unchanged.  Statistical parity only."""
+        import os
+        import ewn_gym_amd
+        first = Player.get_opponent(self.current_player)
+        wins = ewn_gym_amd.playout_wins(self.board.astype(np.int8)[None], first.value, self.num_simulations,
+                                        key=int.from_bytes(os.urandom(8), "little"), cube_layer=self.cube_layer)
+        return int(wins[0].item()) / self.num_simulations
+
     def evaluate(self, heuristic="hybrid"):
         import ewn_gym_amd
         if heuristic == "sim_winrate":
-            raise NotImplementedError("'sim_winrate' (envs/minimax_ewn.py:215-238) is not built")
+            return self.simulate()
         v = float(ewn_gym_amd.evaluate(self.board.astype(np.int8)[None], heuristic, cube_layer=self.cube_layer)[0].item())
         if heuristic != "hybrid" or abs(v) == 10.0:
             return int(v)  # upstream returns Python ints for the integer heuristics and the +-10 terminals

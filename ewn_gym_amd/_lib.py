@@ -22,7 +22,7 @@ INFO_MESSAGES = {
 
 EXPORTS = ["ewn_abi_version", "ewn_strerror", "ewn_rng_words", "ewn_step_scratch_bytes", "ewn_tables_bytes",
            "ewn_build_tables", "ewn_init_aux", "ewn_reset",
-           "ewn_step", "ewn_legal_actions", "ewn_evaluate", "ewn_predict_minimax", "ewn_predict_random",
+           "ewn_step", "ewn_legal_actions", "ewn_apply_action", "ewn_playout_wins", "ewn_evaluate", "ewn_predict_minimax", "ewn_predict_random",
            "ewn_predict_mcts"]
 
 
@@ -87,6 +87,8 @@ def load():
         "ewn_reset": (i32, [cfgp, stp, vp, vp, vp]),
         "ewn_step": (i32, [cfgp, stp, vp, outp, vp, vp]),
         "ewn_legal_actions": (i32, [i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
+        "ewn_apply_action": (i32, [i32, i32, i32, vp, vp, i32, vp, vp, vp, vp]),
+        "ewn_playout_wins": (i32, [i32, i32, i32, vp, i32, i32, u64, vp, vp]),
         "ewn_evaluate": (i32, [i32, i32, i32, vp, i32, vp, vp]),
         "ewn_predict_minimax": (i32, [i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp]),
         "ewn_predict_random": (i32, [i32, i32, i32, vp, vp, u64, u32, vp, i32, vp, vp]),

@@ -392,6 +392,49 @@ __global__ __launch_bounds__(BS) void k_legal(Geom g, int M, const int8_t *board
     if (n_acts) n_acts[m] = (int8_t)n;
 }
 
+template <int SIDE, int NW> EWN_DEV void rollout_ply(const Geom &g, GState<NW> &s, PhiloxStream &ps);
+EWN_DEV int ps_below(PhiloxStream &ps, int n);
+
+template <int NW>
+__global__ __launch_bounds__(BS) void k_apply_action(Geom g, int M, const int8_t *boards, const int8_t *dice, int player,
+                                                     const int8_t *actions, int8_t *new_boards, uint8_t *valid)
+{
+    const int m = blockIdx.x * BS + threadIdx.x;
+    if (m >= M) return;
+    GState<NW> s;
+    decode_board<NW>(g, boards + (size_t)m * g.cells, s);
+    const int d = dice[m], flag = actions[2 * m], dir = actions[2 * m + 1];
+    const u32 alive = player == 1 ? s.aliveP : s.aliveN;
+    bool ok = false;
+    if (alive != 0 && d >= 1 && d <= g.CN && dir >= 0 && dir <= 2) {
+        const int k = cube_to_move(select_cubes(alive, d), flag == 1);
+        if (player == 1) { ok = k >= 0 && dir_ok<0>(g, pos_of<0>(s, k), dir); if (ok) apply_move<0, NW>(g, s, k, dir); }
+        else { ok = k >= 0 && dir_ok<1>(g, pos_of<1>(s, k), dir); if (ok) apply_move<1, NW>(g, s, k, dir); }
+    }
+    encode_board<NW>(g, s, new_boards + (size_t)m * g.cells);
+    if (valid) valid[m] = ok ? 1 : 0;
+}
+
+// MinimaxEnv.simulate, envs/minimax_ewn.py:215-238: one thread per (position, playout)
+template <int NW>
+__global__ __launch_bounds__(BS) void k_playout_wins(Geom g, int M, int n_sims, const int8_t *boards, int first_player, u64 key,
+                                                     int32_t *wins)
+{
+    const long long idx = (long long)blockIdx.x * BS + threadIdx.x;
+    if (idx >= (long long)M * n_sims) return;
+    const int m = (int)(idx / n_sims), r = (int)(idx % n_sims);
+    GState<NW> s;
+    decode_board<NW>(g, boards + (size_t)m * g.cells, s);
+    PhiloxStream ps;
+    ps.init((u32)m, (u32)r, 0x53494D55u, key, 0u);
+    int cur = first_player == 1 ? 0 : 1;
+    for (int ply = 0; ply < 1024 && !is_win<NW>(g, s); ply++) {
+        if (cur == 0) rollout_ply<0, NW>(g, s, ps); else rollout_ply<1, NW>(g, s, ps);
+        cur ^= 1;
+    }
+    if ((s.occP & g.corner_br) || s.occN == 0) atomicAdd(&wins[m], 1);
+}
+
 template <int NW>
 __global__ __launch_bounds__(BS) void k_evaluate(Geom g, int M, const int8_t *boards, int heur, double *out)
 {
@@ -908,6 +951,39 @@ int ewn_legal_actions(int board_size, int cube_layer, int M, const int8_t *board
     hipStream_t s = (hipStream_t)stream;
     BY_NW(g, (k_legal<1><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, player, acts, n_acts, cube_small, cube_large, win)),
           (k_legal<2><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, player, acts, n_acts, cube_small, cube_large, win)));
+    return launch_status();
+}
+
+int ewn_apply_action(int board_size, int cube_layer, int M, const int8_t *boards, const int8_t *dice, int player,
+                     const int8_t *actions, int8_t *new_boards, uint8_t *valid, void *stream)
+{
+    Geom g;
+    int rc = query_geom(board_size, cube_layer, M, boards, g);
+    if (rc) return rc;
+    if (player != 1 && player != 2) return EWN_EINVAL;
+    if (M == 0) return EWN_OK;
+    if (!dice || !actions || !new_boards) return EWN_ENULL;
+    hipStream_t s = (hipStream_t)stream;
+    BY_NW(g, (k_apply_action<1><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, player, actions, new_boards, valid)),
+          (k_apply_action<2><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, player, actions, new_boards, valid)));
+    return launch_status();
+}
+
+int ewn_playout_wins(int board_size, int cube_layer, int M, const int8_t *boards, int first_player, int n_sims, uint64_t key,
+                     int32_t *wins, void *stream)
+{
+    Geom g;
+    int rc = query_geom(board_size, cube_layer, M, boards, g);
+    if (rc) return rc;
+    if ((first_player != 1 && first_player != 2) || n_sims < 1) return EWN_EINVAL;
+    if (g.CN < 6) return EWN_EUNSUPPORTED; // dice 1..6 hard-coded upstream
+    if (M == 0) return EWN_OK;
+    if (!wins) return EWN_ENULL;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(wins, 0, (size_t)M * sizeof(int32_t), s) != hipSuccess) return EWN_ELAUNCH;
+    const long long threads = (long long)M * n_sims;
+    BY_NW(g, (k_playout_wins<1><<<GRID(threads), BS, 0, s>>>(g, M, n_sims, boards, first_player, key, wins)),
+          (k_playout_wins<2><<<GRID(threads), BS, 0, s>>>(g, M, n_sims, boards, first_player, key, wins)));
     return launch_status();
 }
 

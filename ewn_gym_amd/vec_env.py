@@ -171,6 +171,28 @@ def legal_actions(boards, dice, player=1, cube_layer=3):
     return acts, n, cs, cl, win
 
 
+def apply_action(boards, dice, actions, player=1, cube_layer=3):
+    """make_simulated_action on M positions -> (new boards int8 [M,S,S], valid uint8 [M])"""
+    lib = _lib.load()
+    b, d, M, S, dev = _prep(boards, dice)
+    a = torch.as_tensor(actions).reshape(M, 2).to(dev).to(torch.int8).contiguous()
+    nb = torch.zeros_like(b)
+    valid = torch.zeros(M, dtype=torch.uint8, device=dev)
+    check(lib.ewn_apply_action(S, cube_layer, M, _ptr(b), _ptr(d), int(player), _ptr(a), _ptr(nb), _ptr(valid), _stream()),
+          "ewn_apply_action")
+    return nb, valid
+
+
+def playout_wins(boards, first_player, n_sims=100, key=0, cube_layer=3):
+    """MinimaxEnv.simulate on M positions -> int32 [M] playouts won by TOP_LEFT out of n_sims"""
+    lib = _lib.load()
+    b, _, M, S, dev = _prep(boards)
+    wins = torch.zeros(M, dtype=torch.int32, device=dev)
+    check(lib.ewn_playout_wins(S, cube_layer, M, _ptr(b), int(first_player), int(n_sims), C.c_uint64(key), _ptr(wins), _stream()),
+          "ewn_playout_wins")
+    return wins
+
+
 def evaluate(boards, heuristic="hybrid", cube_layer=3):
     lib = _lib.load()
     if heuristic not in HEUR:

@@ -167,6 +167,18 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
 int ewn_legal_actions(int board_size, int cube_layer, int M, const int8_t *boards, const int8_t *dice, int player,
                       int8_t *acts, int8_t *n_acts, int8_t *cube_small, int8_t *cube_large, uint8_t *win, void *stream);
 
+/* make_simulated_action (envs/ewn.py:377-412) on M positions: player (1 TOP_LEFT / 2 BOTTOM_RIGHT) moves the cube its
+ * dice selects ([flag, dir] as in step).  new_boards [M][S*S] receives the position after the move (unchanged when the
+ * move leaves the board); valid [M] (may be NULL) is 1 for a legal move.  The host keeps the undo history. */
+int ewn_apply_action(int board_size, int cube_layer, int M, const int8_t *boards, const int8_t *dice, int player,
+                     const int8_t *actions, int8_t *new_boards, uint8_t *valid, void *stream);
+
+/* MinimaxEnv.simulate (envs/minimax_ewn.py:215-238), the 'sim_winrate' heuristic: n_sims uniformly random playouts
+ * from each position, `first_player` (1/2) moving first; wins [M] = playouts TOP_LEFT won.  Statistical parity only
+ * (the reference draws from an unseeded Python `random`). */
+int ewn_playout_wins(int board_size, int cube_layer, int M, const int8_t *boards, int first_player, int n_sims,
+                     uint64_t key, int32_t *wins, void *stream);
+
 /* MinimaxEnv.evaluate(heuristic) (envs/minimax_ewn.py:29-213) */
 int ewn_evaluate(int board_size, int cube_layer, int M, const int8_t *boards, int heuristic, double *out, void *stream);
 

@@ -291,6 +291,44 @@ def main():
         g10.append({"agent_depth": adepth, "opp": str(opp), "opp_depth": odepth, "scores": scores, "lengths": lengths})
     dump("g10_eval_loop.json", g10)
 
+    # ---- G11: make_simulated_action / undo (envs/ewn.py:377-434) and MinimaxEnv.simulate (minimax_ewn.py:215-238) ---
+    g11 = {"moves": [], "simulate": []}
+    env = envs.MinimaxEnv(board_size=5, cube_layer=3)
+    for board, dice, player in selfplay_positions(5, 3, 12, gen):
+        for pl in (Player.TOP_LEFT, Player.BOTTOM_RIGHT):
+            if not ((board > 0).any() if pl == Player.TOP_LEFT else (board < 0).any()):
+                continue
+            for flag in (0, 1):
+                for d in (0, 1, 2):
+                    env.board[:] = board
+                    env.dice_roll = dice
+                    agent = cp.ExpectiMinimaxAgent(1, 3, 5)
+                    agent.restore_env_with_obs({"board": board, "dice_roll": dice})
+                    e = agent.env
+                    e.history = []
+                    e.make_simulated_action(pl, [flag, d])
+                    after = [int(v) for v in e.board.reshape(-1)]
+                    legal = e.history[-1] is not None
+                    e.undo_simulated_action()
+                    assert (e.board == board).all()
+                    g11["moves"].append({"board": [int(v) for v in board.reshape(-1)], "dice": dice, "player": pl.value,
+                                         "action": [flag, d], "after": after, "legal": legal})
+    import random as _r
+    _r.seed(777)
+    for board, dice, player in selfplay_positions(5, 3, 2, gen)[::3][:8]:
+        agent = cp.ExpectiMinimaxAgent(1, 3, 5)
+        agent.restore_env_with_obs({"board": board, "dice_roll": dice})
+        e = agent.env
+        if e.check_win():
+            continue
+        tot = 0.0
+        reps = 12
+        for _ in range(reps):
+            e.current_player = Player.TOP_LEFT
+            tot += e.simulate()
+        g11["simulate"].append({"board": [int(v) for v in board.reshape(-1)], "winrate": tot / reps, "n": reps * 100})
+    dump("g11_simulated_action.json", g11)
+
     # ---- G9: flat Monte-Carlo statistics ---------------------------------------------------
     import copy
     import random as pyrandom

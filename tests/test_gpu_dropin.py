@@ -179,3 +179,50 @@ def test_sb3_vec_env_adapter_contract():
     assert seen_terminal > N
     with pytest.raises(ea.EwnError):
         EWNVecEnv(ea.VecEWN(4))
+
+
+def test_make_and_undo_simulated_action(golden):
+    """envs/ewn.py:377-434 through the drop-in env (the move itself is the ewn_apply_action kernel)."""
+    import envs
+    from constants import Player
+    env = envs.MinimaxEnv()
+    g = golden("g11_simulated_action.json")
+    for r in g["moves"][::3]:
+        before = np.array(r["board"]).reshape(5, 5)
+        env.board[:] = before
+        env.set_dice_roll(r["dice"])
+        env.history = []
+        env.make_simulated_action(Player(r["player"]), r["action"])
+        assert env.board.reshape(-1).tolist() == r["after"]
+        assert (env.history[-1] is not None) == r["legal"]
+        env.undo_simulated_action()
+        assert np.array_equal(env.board, before) and env.history == []
+
+
+def test_apply_action_batched(golden):
+    import ewn_gym_amd as ea
+    g = golden("g11_simulated_action.json")["moves"]
+    for pl in (1, 2):
+        recs = [r for r in g if r["player"] == pl]
+        nb, valid = ea.apply_action(np.array([r["board"] for r in recs], np.int8).reshape(-1, 5, 5), [r["dice"] for r in recs],
+                                    [r["action"] for r in recs], player=pl)
+        assert nb.cpu().numpy().reshape(len(recs), -1).tolist() == [r["after"] for r in recs]
+        assert valid.cpu().numpy().astype(bool).tolist() == [r["legal"] for r in recs]
+
+
+def test_sim_winrate_heuristic_statistics(golden):
+    """MinimaxEnv.simulate / evaluate('sim_winrate') (envs/minimax_ewn.py:215-238): statistical parity, 5 sigma."""
+    import ewn_gym_amd as ea
+    g = golden("g11_simulated_action.json")["simulate"]
+    boards = np.array([r["board"] for r in g], np.int8).reshape(-1, 5, 5)
+    n = 4000
+    wins = ea.playout_wins(boards, first_player=2, n_sims=n, key=5).cpu().numpy()   # current_player TOP_LEFT -> BOTTOM_RIGHT moves first
+    for r, w in zip(g, wins):
+        p = (r["winrate"] * r["n"] + w) / (r["n"] + n)
+        sigma = max(1e-9, (p * (1 - p) * (1 / r["n"] + 1 / n)) ** 0.5)
+        assert abs(r["winrate"] - w / n) <= 5 * sigma + 1e-9
+    import envs
+    env = envs.MinimaxEnv()
+    env.board[:] = boards[0]
+    v = env.evaluate("sim_winrate")
+    assert 0.0 <= v <= 1.0
