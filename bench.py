@@ -180,7 +180,7 @@ def main():
             traffic = valu = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tpath) and N == 65536 and args.board_size == 5:
-                try:   # PMC results of this kernel at this size, collected by tools_pmc.sh in separate rocprofv3 passes
+                try:   # PMC results of this kernel at this size, collected by tools/pmc_passes.sh in separate rocprofv3 passes
                     pmc = json.load(open(tpath))
                     key = "%s_d%d_%s" % (args.opponent, args.max_depth, args.rng)
                     traffic = pmc.get(key)

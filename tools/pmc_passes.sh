@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <tag> <bench args...>   (run on the GPU box from the repo root)
+# usage: tools/pmc_passes.sh <tag> <bench args...>   (run on the GPU box from the repo root)
 # Separate passes for FETCH_SIZE and WRITE_SIZE (TCC slot budget, MI355X_MICROARCH.md "rocprofv3 PMC slots").
 set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
