@@ -353,7 +353,7 @@ EWN_DEV void mt_fill_window(u32 seed, int W, u32 *win)
 // Output n of the same stream for W <= n < 454, memory-free (rare path: an episode
 // that consumes more draws than the window holds).  For 227 <= n < 454 the word
 // x[n+397] is itself a first-generation output of the recurrence.
-__device__ __noinline__ u32 mt_output_closed(u32 seed, u32 n)
+EWN_DEV u32 mt_output_closed(u32 seed, u32 n)
 {
     const u32 j = n >= 227u ? n - 227u : 0u;
     u32 s = seed, sn = 0, sn1 = 0, sj = 0, sj1 = 0, sj397 = 0, sn397 = 0;
@@ -370,25 +370,60 @@ __device__ __noinline__ u32 mt_output_closed(u32 seed, u32 n)
     return mt_temper(x397 ^ mt_twist(sn, sn1));
 }
 
-#define EWN_RNG_HDR 4 // header words per lane: seed, draw index, next_seed, flags
-#define RNGF_OVERFLOW 1u  // MT draw index >= 454 in one episode: unsupported (never observed)
-#define RNGF_SLOT 2u      // which of the lane's two MT windows belongs to the current episode
-#define RNGF_SPARE 4u     // the other window already holds the outputs for seed `next_seed`
-#define RNGF_NEED 8u      // the spare window was consumed by an auto-reset: k_mt_refill must rebuild it
-
-// ewn_state.rng holds N headers (uint4 each, one coalesced 16-byte access per lane) followed, for the MT kind, by
-// N x 2 windows of W tempered MT19937 outputs: the current episode's and, prepared ahead of time by k_mt_refill,
-// the next episode's -- so an auto-reset inside the step kernel is a slot flip, not a 500-step recurrence.
-EWN_DEV uint4 *rng_hdr_ptr(u32 *rng, int lane) { return (uint4 *)rng + lane; }
-EWN_DEV u32 *rng_win_ptr(u32 *rng, int N, u32 W, int lane, u32 flags)
+// One MT19937 window: np.random.seed(seed)'s first W outputs into dst.  The seeding recurrence (397+W dependent
+// multiply-adds) runs in registers with its W+1 saved words in LDS ([word][thread], row stride 65: conflict-free).
+EWN_DEV void mt_window_lds(u32 seed, u32 W, u32 *sm, int t, u32 *dst)
 {
-    return rng + (size_t)N * EWN_RNG_HDR + ((size_t)lane * 2 + ((flags & RNGF_SLOT) ? 1 : 0)) * W;
+    u32 s = seed;
+    for (u32 i = 0; i <= W; i++) { sm[i * 65 + t] = s; s = 1812433253u * (s ^ (s >> 30)) + i + 1u; }  // s[0..W]
+    for (u32 i = W + 1; i < 397; i++) s = 1812433253u * (s ^ (s >> 30)) + i + 1u;                       // -> s[397]
+    u32 a = sm[t];
+    #pragma unroll 8
+    for (u32 n = 0; n < W; n++) {   // output n = temper(s[397+n] ^ twist(s[n], s[n+1]))
+        const u32 b = sm[(n + 1) * 65 + t];
+        dst[n] = mt_temper(s ^ mt_twist(a, b));
+        s = 1812433253u * (s ^ (s >> 30)) + (397u + n) + 1u;
+        a = b;
+    }
 }
 
 EWN_DEV u32 fmix32(u32 h) // MurmurHash3 finaliser
 {
     h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
     return h;
+}
+
+#define EWN_RNG_HDR 4 // header words per lane: seed, draw index, next_seed, flags
+// flags word (MT kind): episode e of a lane lives in window slot e % 3; the two other slots hold, or are about to hold,
+// the windows of episodes e+1 and e+2, so an auto-reset is a rotation, not a 500-step recurrence.
+#define RNGF_OVERFLOW 1u                 // MT draw index >= 454 in one episode: unsupported (never observed)
+#define RNGF_CUR(f) (((f) >> 4) & 3u)    // slot of the current episode
+#define RNGF_READY(f) (((f) >> 8) & 3u)  // how many of the next episodes' windows are complete (0..2)
+#define RNGF_X(f) (((f) >> 10) & 3u)     // slots freed during the previous step kernel: their refill is running now
+#define RNGF_Y(f) (((f) >> 12) & 3u)     // slots freed two kernels ago: refilled during the previous kernel, usable now
+EWN_DEV u32 rngf_make(u32 ovf, u32 cur, u32 ready, u32 x, u32 y) { return (ovf & 1u) | (cur << 4) | (ready << 8) | (x << 10) | (y << 12); }
+
+// ewn_state.rng layout: N headers (uint4 each, one coalesced 16-byte access per lane); for the MT kind then N x 3
+// windows of W tempered MT19937 outputs and N reset-epoch words (a lane's explicit reset invalidates queued refills).
+EWN_DEV uint4 *rng_hdr_ptr(u32 *rng, int lane) { return (uint4 *)rng + lane; }
+EWN_DEV u32 *rng_win_ptr(u32 *rng, int N, u32 W, int lane, u32 slot)
+{
+    return rng + (size_t)N * EWN_RNG_HDR + ((size_t)lane * 3 + slot) * W;
+}
+EWN_DEV u32 *rng_epoch_ptr(u32 *rng, int N, u32 W, int lane) { return rng + (size_t)N * EWN_RNG_HDR + (size_t)N * 3 * W + lane; }
+
+// Window refills handed from one step launch to the next (k_step_d3): step block b of a launch parks its requests
+// {lane | slot << 30, seed, epoch, 0} in ITS OWN region of list[phase] and stores how many in cnt[phase][b] -- plain
+// stores, no atomics; the refill blocks of the next launch read list[phase ^ 1]; k_mtq_flip toggles phase in between.
+struct MtQueue { u32 *ctrl; u32 *cnt; uint4 *list; int nblk, nb4, per_blk; };
+EWN_DEV MtQueue mtq_make(void *scratch, int nblk, int per_blk)
+{
+    MtQueue q;
+    q.nblk = nblk; q.nb4 = (nblk + 3) & ~3; q.per_blk = per_blk;
+    q.ctrl = (u32 *)scratch;                   // [0] = phase
+    q.cnt = q.ctrl + 4;                        // [2][nb4]
+    q.list = (uint4 *)(q.cnt + 2 * q.nb4);     // [2][nblk][per_blk]
+    return q;
 }
 
 // The fused stand-in agent's randomness (ewn_step_out.random_action): one 32-bit hash per (episode, draws so far, lane)
@@ -418,17 +453,19 @@ struct LaneRng {
     PhiloxStream ps;
     // MT kind: the next 8 window words, fetched in one round trip when the lane is loaded, so the masked-rejection
     // loop of randint does not serialise a global load per iteration (scalars, not an array: no scratch)
-    u32 pre_base, p0, p1, p2, p3, p4, p5, p6, p7;
+    u32 pre_base, pre_lim, p0, p1, p2, p3, p4, p5, p6, p7;
+    u32 q0, q1, q2, q3; // first words of the NEXT episode's window, fetched with the rest (prefetch_next)
+    bool q_valid;
     EWN_DEV void prefetch()
     {
-        pre_base = n;
+        pre_base = n; pre_lim = 8u;
         if (kind == 0 && n + 8u <= W) { p0 = win[n]; p1 = win[n + 1]; p2 = win[n + 2]; p3 = win[n + 3]; p4 = win[n + 4]; p5 = win[n + 5]; p6 = win[n + 6]; p7 = win[n + 7]; }
         else pre_base = 0xFFFFFFF0u; // nothing cached
     }
     EWN_DEV void load(int kind_, uint4 h, const u32 *win_, u32 W_, u64 key)
     {
         kind = kind_; seed = h.x; n = h.y; next_seed = h.z; flags = h.w; W = W_; win = win_;
-        p0 = p1 = p2 = p3 = p4 = p5 = p6 = p7 = 0; pre_base = 0xFFFFFFF0u;
+        p0 = p1 = p2 = p3 = p4 = p5 = p6 = p7 = 0; pre_base = 0xFFFFFFF0u; pre_lim = 8u; q0 = q1 = q2 = q3 = 0; q_valid = false;
         if (kind == 1) ps.init(seed, 0u, 0x454E5631u, key, n);
     }
     EWN_DEV uint4 header() const { return make_uint4(seed, kind == 1 ? ps.n : n, next_seed, flags); }
@@ -438,7 +475,7 @@ struct LaneRng {
         if (kind == 1) return ps.next();
         u32 v;
         const u32 j = n - pre_base;
-        if (j < 8u) {
+        if (j < pre_lim) {
             const u32 a = (j & 1u) ? p1 : p0, b = (j & 1u) ? p3 : p2, c = (j & 1u) ? p5 : p4, d = (j & 1u) ? p7 : p6;
             const u32 ab = (j & 2u) ? b : a, cd = (j & 2u) ? d : c;
             v = (j & 4u) ? cd : ab;
@@ -451,20 +488,50 @@ struct LaneRng {
     }
     // np.random.randint(lo, hi) of the legacy RandomState: masked rejection on 32-bit
     // draws; a one-element range consumes no draw.
-    // Start the next episode (seed = next_seed).  MT kind: flip to the window prepared by k_mt_refill and flag the
-    // lane for the next refill; if the spare is not ready (auto-reset without refills in between) rebuild in place.
-    EWN_DEV void next_episode(u32 *rng, int N, int lane, u32 stride, u64 key)
+    // Once per step kernel: what was freed two kernels ago has been refilled by now.
+    EWN_DEV void begin_kernel()
+    {
+        if (kind == 0) flags = rngf_make(flags, RNGF_CUR(flags), min(2u, RNGF_READY(flags) + RNGF_Y(flags)), 0u, RNGF_X(flags));
+    }
+    // speculative: the head of the next episode's window, so an auto-reset does not wait for a dependent load
+    EWN_DEV void prefetch_next(u32 *rng, int N, int lane)
+    {
+        if (kind == 0 && RNGF_READY(flags) >= 1u) {
+            const u32 *w = rng_win_ptr(rng, N, W, lane, (RNGF_CUR(flags) + 1u) % 3u);
+            q0 = w[0]; q1 = w[1]; q2 = w[2]; q3 = w[3]; q_valid = true;
+        }
+    }
+    // Start the next episode (seed = next_seed).  MT kind: rotate to the next window slot and ask for the freed slot to
+    // be refilled with the window of episode e+3 -- through `pend` when the caller queues refills for the next kernel
+    // (k_step_d3), else by leaving X > 0 for k_mt_refill.  If no future window is complete (cannot happen while refills
+    // keep up; kept correct anyway) the current slot is rebuilt in place and both other slots are re-requested.
+    struct Pending { u32 n, slot0, seed0, slot1, seed1; }; // scalars, not arrays: a runtime-indexed array would live in scratch
+    EWN_DEV void next_episode(u32 *rng, int N, int lane, u32 stride, u64 key, Pending *pend)
     {
         const u32 s2 = next_seed;
-        u32 f = flags & ~RNGF_OVERFLOW;
+        u32 f = flags;
+        if (pend) { pend->n = 0; pend->slot0 = pend->slot1 = pend->seed0 = pend->seed1 = 0; }
         if (kind == 0) {
-            if (f & RNGF_SPARE) {
-                f = ((f ^ RNGF_SLOT) & ~RNGF_SPARE) | RNGF_NEED;
+            const u32 cur = RNGF_CUR(f), ready = RNGF_READY(f);
+            if (ready >= 1u) {
+                f = rngf_make(0u, (cur + 1u) % 3u, ready - 1u, RNGF_X(f) + 1u, RNGF_Y(f));
+                if (pend) { pend->n = 1; pend->slot0 = cur; pend->seed0 = s2 + 2u * stride; }
+                const u32 a0 = q0, a1 = q1, a2 = q2, a3 = q3;
+                const bool spec = q_valid;
+                load(kind, make_uint4(s2, 0u, s2 + stride, f), rng_win_ptr(rng, N, W, lane, RNGF_CUR(f)), W, key);
+                if (!spec) { prefetch(); return; }
+                // the first dice of the new episode comes out of the speculatively fetched words; anything beyond them
+                // (three masked rejections in a row) falls back to the window in memory
+                pre_base = 0u; p0 = a0; p1 = a1; p2 = a2; p3 = a3; p4 = p5 = p6 = p7 = 0; pre_lim = 4u;
+                return;
             } else {
-                mt_fill_window(s2, (int)W, rng_win_ptr(rng, N, W, lane, f));
+                mt_fill_window(s2, (int)W, rng_win_ptr(rng, N, W, lane, cur));
+                f = rngf_make(0u, cur, 0u, 2u, 0u);
+                if (pend) { pend->n = 2; pend->slot0 = (cur + 1u) % 3u; pend->seed0 = s2 + stride;
+                            pend->slot1 = (cur + 2u) % 3u; pend->seed1 = s2 + 2u * stride; }
             }
-        }
-        load(kind, make_uint4(s2, 0u, s2 + stride, f), rng_win_ptr(rng, N, W, lane, f), W, key);
+        } else f = 0;
+        load(kind, make_uint4(s2, 0u, s2 + stride, f), rng_win_ptr(rng, N, W, lane, RNGF_CUR(f)), W, key);
         prefetch();
     }
     EWN_DEV void begin_step() { if (kind == 1) ps.n = (ps.n + 3u) & ~3u; }

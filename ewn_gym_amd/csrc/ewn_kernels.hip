@@ -77,57 +77,46 @@ __device__ __forceinline__ void tables_to_lds(int8_t *lds, const int8_t *g)
 // ---------------------------------------------------------------- per-lane pieces
 
 // reset(seed) + setup_game, envs/ewn.py:488-494, 94-108, for an explicitly given seed: builds the window of this
-// episode and, ahead of time, of the next one (seed + stride)
+// episode and, ahead of time, of the next two (seed + stride, seed + 2 stride)
 template <int NW>
 EWN_DEV void lane_reset(const Geom &g, const KCfg &c, u32 *rng, int lane, u32 seed, GState<NW> &s, int &dice, LaneRng &r)
 {
     u32 f = 0;
     if (c.rng_kind == 0) {
-        mt_fill_window(seed, (int)c.W, rng_win_ptr(rng, c.N, c.W, lane, 0u));
-        mt_fill_window(seed + c.seed_stride, (int)c.W, rng_win_ptr(rng, c.N, c.W, lane, RNGF_SLOT));
-        f = RNGF_SPARE;
+        for (u32 j = 0; j < 3; j++) mt_fill_window(seed + j * c.seed_stride, (int)c.W, rng_win_ptr(rng, c.N, c.W, lane, j));
+        f = rngf_make(0u, 0u, 2u, 0u, 0u);
+        *rng_epoch_ptr(rng, c.N, c.W, lane) += 1u; // refills queued for this lane before the reset are now stale
     }
-    r.load(c.rng_kind, make_uint4(seed, 0u, seed + c.seed_stride, f), rng_win_ptr(rng, c.N, c.W, lane, f), c.W, c.key);
+    r.load(c.rng_kind, make_uint4(seed, 0u, seed + c.seed_stride, f), rng_win_ptr(rng, c.N, c.W, lane, 0u), c.W, c.key);
     init_state<NW>(g, s);
     dice = r.first_dice(g.CN); // roll_dice :90-91
 }
 
-// the auto-reset inside a step: next_seed becomes the episode seed
+// the auto-reset inside a step: next_seed becomes the episode seed (the freed window is rebuilt by k_mt_refill afterwards)
 template <int NW>
-EWN_DEV void lane_auto_reset(const Geom &g, const KCfg &c, u32 *rng, int lane, const KScratch &sc, GState<NW> &s, int &dice, LaneRng &r)
+EWN_DEV void lane_auto_reset(const Geom &g, const KCfg &c, u32 *rng, int lane, GState<NW> &s, int &dice, LaneRng &r)
 {
-    r.next_episode(rng, c.N, lane, c.seed_stride, c.key);
+    r.next_episode(rng, c.N, lane, c.seed_stride, c.key, nullptr);
     init_state<NW>(g, s);
     dice = r.first_dice(g.CN);
 }
 
-// Rebuild the spare MT window of every lane whose header carries RNGF_NEED (set by an auto-reset): one thread per
-// lane, coalesced header reads, waves without a flagged lane leave at once.  The seeding recurrence (397+W dependent
-// multiply-adds, ~7 us of pure latency) runs in registers with its W+1 saved words in LDS ([word][thread], row stride
-// 65: conflict-free).  No queue, no atomics: a single hot counter serialised the ~7 000 appends per step in L2.
+// Generic step path: right after the step kernel, rebuild the window slots it freed (header field X > 0) and count
+// them ready.  One thread per lane, coalesced header reads, waves without a flagged lane leave at once.
 #define REFILL_BS 64
-__global__ __launch_bounds__(REFILL_BS) void k_mt_refill(u32 *rng, int N, u32 W)
+__global__ __launch_bounds__(REFILL_BS) void k_mt_refill(u32 *rng, int N, u32 W, u32 stride)
 {
     extern __shared__ u32 sm[]; // (W + 1) rows of 65 words
     const int t = threadIdx.x, lane = blockIdx.x * REFILL_BS + t;
     uint4 h = make_uint4(0u, 0u, 0u, 0u);
     if (lane < N) h = *rng_hdr_ptr(rng, lane);
-    const bool act = (h.w & RNGF_NEED) != 0;
-    if (!__any(act)) return;
-    if (!act) return;
-    u32 s = h.z; // the NEXT episode's seed
-    for (u32 i = 0; i <= W; i++) { sm[i * 65 + t] = s; s = 1812433253u * (s ^ (s >> 30)) + i + 1u; }  // s[0..W]
-    for (u32 i = W + 1; i < 397; i++) s = 1812433253u * (s ^ (s >> 30)) + i + 1u;                       // -> s[397]
-    u32 *dst = rng_win_ptr(rng, N, W, lane, h.w ^ RNGF_SLOT);
-    u32 a = sm[t];
-    #pragma unroll 8
-    for (u32 n = 0; n < W; n++) {   // output n = temper(s[397+n] ^ twist(s[n], s[n+1]))
-        const u32 b = sm[(n + 1) * 65 + t];
-        dst[n] = mt_temper(s ^ mt_twist(a, b));
-        s = 1812433253u * (s ^ (s >> 30)) + (397u + n) + 1u;
-        a = b;
-    }
-    rng_hdr_ptr(rng, lane)->w = (h.w & ~RNGF_NEED) | RNGF_SPARE;
+    const u32 x = RNGF_X(h.w);
+    if (!__any(x != 0u)) return;
+    if (x == 0u) return;
+    const u32 cur = RNGF_CUR(h.w);
+    for (u32 j = 1; j <= x; j++) // the slot freed j resets ago will serve episode e + 3 - j
+        mt_window_lds(h.x + (3u - j) * stride, W, sm, t, rng_win_ptr(rng, N, W, lane, (cur + 3u - j) % 3u));
+    rng_hdr_ptr(rng, lane)->w = rngf_make(h.w, cur, min(2u, RNGF_READY(h.w) + x), 0u, RNGF_Y(h.w));
 }
 
 struct StepRes { double reward; int term, trunc, info; };
@@ -297,7 +286,8 @@ __global__ __launch_bounds__(BS) void k_step(Geom g, KCfg c, KState st, const in
                 if (out.tdice) out.tdice[lane] = (int8_t)dice;
                 if (out.ract) ((uint16_t *)out.ract)[lane] = 0;
             } else {
-                LaneRng r; r.load(c.rng_kind, hdr, rng_win_ptr(st.rng, c.N, c.W, lane, hdr.w), c.W, c.key);
+                LaneRng r; r.load(c.rng_kind, hdr, rng_win_ptr(st.rng, c.N, c.W, lane, RNGF_CUR(hdr.w)), c.W, c.key);
+                if (PHASE != 2) r.begin_kernel();
                 r.prefetch();
                 if (PHASE != 2) r.begin_step();
                 GState<NW> s;
@@ -330,7 +320,7 @@ __global__ __launch_bounds__(BS) void k_step(Geom g, KCfg c, KState st, const in
                     if (out.tdice) out.tdice[lane] = (int8_t)dice;
                     if (o.term) {
                         if (c.autoreset) {
-                            lane_auto_reset<NW>(g, c, st.rng, lane, sc, s, dice, r);
+                            lane_auto_reset<NW>(g, c, st.rng, lane, s, dice, r);
                             if (c.shaped && c.refresh && st.prev_score) st.prev_score[lane] = evaluate<NW>(g, s, EWN_H_HYBRID);
                         } else st.done[lane] = 1;
                     }
@@ -687,7 +677,7 @@ static int check_cfg(const ewn_config *cfg, Geom &g, KCfg &k)
     k.rng_kind = cfg->rng_kind; k.shaped = cfg->shaped; k.autoreset = cfg->autoreset; k.refresh = cfg->shaped_refresh_on_reset;
     k.lane_offset = cfg->lane_offset; k.nsim_total = cfg->num_simulations * cfg->num_env_copies;
     k.seed_stride = cfg->seed_stride; k.W = W;
-    k.rng_words = EWN_RNG_HDR + (cfg->rng_kind == EWN_RNG_MT19937 ? 2u * W : 0u);
+    k.rng_words = EWN_RNG_HDR + (cfg->rng_kind == EWN_RNG_MT19937 ? 3u * W + 1u : 0u);
     k.reward = cfg->reward; k.illegal_reward = cfg->illegal_move_reward; k.key = cfg->philox_key;
     return EWN_OK;
 }
@@ -785,14 +775,22 @@ int ewn_rng_words(const ewn_config *cfg)
     return rc ? rc : (int)k.rng_words;
 }
 
+// the lean kernel's MT refill hand-off (ewn_core.hpp MtQueue), sized for the smallest games-per-block (T = 4)
+static int64_t mtq_bytes(int64_t N)
+{
+    const int64_t gpb = D3_BS / 4, nblk = (N + gpb - 1) / gpb, nb4 = (nblk + 3) / 4 * 4;
+    return 16 + 2 * nb4 * 4 + 2 * nblk * (2 * gpb) * 16;
+}
+
 int64_t ewn_step_scratch_bytes(const ewn_config *cfg)
 {
     Geom g; KCfg k;
     const int rc = check_cfg(cfg, g, k);
     if (rc) return rc;
-    if (cfg->opponent_kind != EWN_OPP_MCTS) return 0;
-    // phase u8 | cdice i8 | act i8x2 | (pad to 8) | obs_id u32 | wins i32x6 | cboard i8[cells]
     const int64_t N = k.N;
+    if (cfg->opponent_kind != EWN_OPP_MCTS)   // MT kind with auto-reset: the refill queue of the lean step kernel (ewn_step_d3.hpp)
+        return (cfg->rng_kind == EWN_RNG_MT19937 && cfg->autoreset) ? mtq_bytes(k.N) : 0;
+    // phase u8 | cdice i8 | act i8x2 | (pad to 8) | obs_id u32 | wins i32x6 | cboard i8[cells]
     return ((N * 4 + 7) / 8) * 8 + N * 4 + N * 24 + N * g.cells;
 }
 
@@ -873,6 +871,7 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
     KScratch sc = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     // MT kind with auto-reset: the step kernel flags the lanes whose spare window it consumed; k_mt_refill rebuilds them right after
     const bool refill = cfg->rng_kind == EWN_RNG_MT19937 && cfg->autoreset;
+    bool lean_fused_refill = false;
     if (cfg->opponent_kind == EWN_OPP_MCTS) {
         if (!scratch) return EWN_ENULL;
         carve_scratch(g, k, scratch, sc);
@@ -885,14 +884,24 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
         if ((fast || lean_random) && !cfg->shaped && d3_threads_per_game(k.N) > 0) {
             // the lean fused kernel: canonical ring space end to end, T lanes per game (ewn_step_d3.hpp)
             const int T = lean_random ? 1 : d3_threads_per_game(k.N);
-            D3Cfg dc = { k.N, k.rng_kind, k.autoreset, k.lane_offset, k.seed_stride, k.W, k.reward, k.key };
+            const int gpb0 = D3_BS / T, step_blocks = (k.N + gpb0 - 1) / gpb0;
+            // MT kind with auto-reset: window refills are extra blocks of the same launch (needs the caller's scratch)
+            const bool fused_refill = refill && scratch != nullptr;
+            lean_fused_refill = fused_refill;
+            const int refill_blocks = fused_refill ? 256 : 0;
+            D3Cfg dc = { k.N, k.rng_kind, k.autoreset, k.lane_offset, refill_blocks, k.seed_stride, k.W, k.reward, k.key };
             D3Buf db = { st->board, st->dice, st->done, st->rng, st->tables, actions, out->reward, out->terminated,
-                         out->truncated, out->info, out->terminal_board, out->terminal_dice, out->random_action };
-            const int gpb = D3_BS / T;
-            const dim3 grid((unsigned)((k.N + gpb - 1) / gpb));
-            const size_t l3 = (((size_t)2 * gpb * g.cells + 15) & ~(size_t)15);
-#define D3_LAUNCH(SS, TT, OO) do { if (k.rng_kind == 0) k_step_d3<SS, TT, OO, 0><<<grid, D3_BS, l3 + FAST_TAB_BYTES(SS), s>>>(dc, db); \
-                                   else k_step_d3<SS, TT, OO, 1><<<grid, D3_BS, l3 + FAST_TAB_BYTES(SS), s>>>(dc, db); } while (0)
+                         out->truncated, out->info, out->terminal_board, out->terminal_dice, out->random_action,
+                         fused_refill ? scratch : nullptr };
+            const int gpb = gpb0;
+            const dim3 grid((unsigned)(step_blocks + refill_blocks));
+            // LDS: boards + terminal boards | tables | (MT) this block's parked refill requests; a refill block needs (W+1) x 65 words
+            size_t l3 = (((size_t)2 * gpb * g.cells + 15) & ~(size_t)15);
+            if (fused_refill) l3 += 16 + (size_t)2 * gpb * 16;
+            const size_t need_refill = fused_refill ? (size_t)(k.W + 1) * 65 * 4 : 0;
+#define D3_LDS(SS) (l3 + FAST_TAB_BYTES(SS) > need_refill ? l3 + FAST_TAB_BYTES(SS) : need_refill)
+#define D3_LAUNCH(SS, TT, OO) do { if (k.rng_kind == 0) k_step_d3<SS, TT, OO, 0><<<grid, D3_BS, D3_LDS(SS), s>>>(dc, db); \
+                                   else k_step_d3<SS, TT, OO, 1><<<grid, D3_BS, D3_LDS(SS), s>>>(dc, db); } while (0)
 #define D3_BY_T(SS) do { if (lean_random) D3_LAUNCH(SS, 1, 1); else if (T == 1) D3_LAUNCH(SS, 1, 0); else if (T == 2) D3_LAUNCH(SS, 2, 0); else D3_LAUNCH(SS, 4, 0); } while (0)
             switch (g.S) {
             case 5: D3_BY_T(5); break;
@@ -924,8 +933,11 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
     }
     rc = launch_status();
     if (rc) return rc;
-    if (refill) {
-        k_mt_refill<<<dim3((unsigned)((k.N + REFILL_BS - 1) / REFILL_BS)), REFILL_BS, (size_t)(k.W + 1) * 65 * 4, s>>>(st->rng, k.N, k.W);
+    if (lean_fused_refill) {
+        k_mtq_flip<<<1, 64, 0, s>>>((u32 *)scratch);
+        rc = launch_status();
+    } else if (refill) {
+        k_mt_refill<<<dim3((unsigned)((k.N + REFILL_BS - 1) / REFILL_BS)), REFILL_BS, (size_t)(k.W + 1) * 65 * 4, s>>>(st->rng, k.N, k.W, k.seed_stride);
         rc = launch_status();
     }
     return rc;

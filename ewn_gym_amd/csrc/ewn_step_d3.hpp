@@ -243,7 +243,7 @@ __device__ __forceinline__ double fast_d3(const FastTab<S> *Tb, const GState<1> 
 // ---------------------------------------------------------------- the fused step kernel
 
 struct D3Cfg {
-    int N, rng_kind, autoreset, lane_offset;
+    int N, rng_kind, autoreset, lane_offset, refill_blocks; // the first refill_blocks blocks of the grid rebuild MT windows (fused MT path), else 0
     u32 seed_stride, W;
     double reward;
     u64 key;
@@ -252,6 +252,7 @@ struct D3Cfg {
 struct D3Buf {
     int8_t *board; int8_t *dice; uint8_t *done; u32 *rng; const void *tables; const int8_t *actions;
     double *reward; uint8_t *terminated; uint8_t *truncated; uint8_t *info; int8_t *tboard; int8_t *tdice; int8_t *ract;
+    void *mtq; // MT kind with auto-reset: the refill hand-off area (scratch), else NULL
 };
 
 #define D3_BS 256
@@ -324,6 +325,9 @@ EWN_DEV void d3_init_state(const FastTab<S> *Tb, RState<S> &s)
 
 // EinsteinWuerfeltNichtEnv.step (envs/ewn.py:436-486), minimax(depth 3, hybrid) opponent, cube_layer 3.
 // T lanes per game; lanes of a group run identical code on identical data except inside d3_search.
+// Between two fused MT launches: the list just produced becomes the one to consume.
+__global__ void k_mtq_flip(u32 *ctrl) { if (threadIdx.x == 0 && blockIdx.x == 0) ctrl[0] ^= 1u; }
+
 // OPP 0: ExpectiMinimaxAgent(max_depth=3, 'hybrid') reply;  OPP 1: RandomAgent reply (classical_policies/random_policy.py:11-15)
 // RNGK: the dice RNG kind as a compile-time constant, so each instantiation carries only its own generator's registers
 template <int S, int T, int OPP, int RNGK>
@@ -331,12 +335,47 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
 {
     constexpr int CELLS = S * S, GPB = D3_BS / T; // games per block
     extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+    // ---- MT kind with auto-reset: window refills ride along in this launch.  The step blocks of the PREVIOUS launch
+    // parked (lane, slot, seed) requests in list[phase ^ 1]; the first refill_blocks blocks of THIS launch rebuild those
+    // windows while the step blocks run (the 397+W-step recurrence is pure latency: hidden behind the step instead of
+    // serialised after it).  Nobody reads a window before the launch after the one that rebuilt it (header fields
+    // READY / X / Y, ewn_core.hpp); k_mtq_flip toggles `phase` between launches; no atomics anywhere.
+    [[maybe_unused]] MtQueue Q;
+    [[maybe_unused]] u32 phase = 0;
+    if constexpr (RNGK == 0) {
+        if (B.mtq) {
+            const int step_blocks = (int)gridDim.x - c.refill_blocks;
+            Q = mtq_make(B.mtq, step_blocks, 2 * GPB);
+            phase = Q.ctrl[0] & 1u;
+            if ((int)blockIdx.x < c.refill_blocks) {
+                if (threadIdx.x < 64) {
+                    // a latency-bound dependent chain that shares its SIMD with busy step waves: let it win arbitration
+                    __builtin_amdgcn_s_setprio(3);
+                    const u32 *cnt = Q.cnt + (size_t)(phase ^ 1u) * Q.nb4;
+                    // refill block j serves the regions of step blocks j, j + refill_blocks, ...
+                    for (int sb = (int)blockIdx.x; sb < step_blocks; sb += c.refill_blocks) {
+                        const u32 n = min(cnt[sb], (u32)Q.per_blk);
+                        const uint4 *list = Q.list + ((size_t)(phase ^ 1u) * Q.nblk + sb) * Q.per_blk;
+                        for (u32 e = threadIdx.x; e < n; e += 64u) {
+                            const uint4 q = list[e];
+                            const int lane = (int)(q.x & 0x3FFFFFFFu);
+                            if (q.z == *rng_epoch_ptr(B.rng, c.N, c.W, lane)) // not invalidated by an explicit reset
+                                mt_window_lds(q.y, c.W, (u32 *)lds, threadIdx.x, rng_win_ptr(B.rng, c.N, c.W, lane, q.x >> 30));
+                        }
+                    }
+                }
+                return;
+            }
+        }
+    }
     int8_t *lds_t = lds + GPB * CELLS;
     int8_t *tb = lds + ((2 * GPB * CELLS + 15) & ~15);
     tables_to_lds<FAST_TAB_BYTES(S)>(tb, (const int8_t *)B.tables); // LDS-DMA, waited for at the barrier
     const FastTab<S> *Tb = (const FastTab<S> *)tb;
+    [[maybe_unused]] u32 *qlds = (u32 *)(tb + FAST_TAB_BYTES(S)); // [0] = requests parked by this block, then up to 2*GPB x uint4
+    if constexpr (RNGK == 0) { if (B.mtq && threadIdx.x == 0) qlds[0] = 0; }
 
-    const int g0 = blockIdx.x * GPB, ng = min(GPB, c.N - g0);
+    const int g0 = ((int)blockIdx.x - c.refill_blocks) * GPB, ng = min(GPB, c.N - g0);
     const int gl = threadIdx.x / T, sub = threadIdx.x % T, game = g0 + gl;
     const bool live = game < c.N, writer = sub == 0;
 
@@ -357,8 +396,11 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
     double reward = 0.0;
     int term = 0, trunc = 0, info = EWN_INFO_NONE;
     RState<S> s;
-    LaneRng r; r.load(RNGK, hdr, rng_win_ptr(B.rng, c.N, c.W, live ? game : 0, hdr.w), c.W, c.key);
+    LaneRng r; r.load(RNGK, hdr, rng_win_ptr(B.rng, c.N, c.W, live ? game : 0, RNGF_CUR(hdr.w)), c.W, c.key);
+    r.begin_kernel();
     r.prefetch();
+    [[maybe_unused]] u32 epoch = 0;
+    if constexpr (RNGK == 0) { if (live) { r.prefetch_next(B.rng, c.N, game); epoch = *rng_epoch_ptr(B.rng, c.N, c.W, game); } }
     r.begin_step();
     d3_decode<S, T>(live ? mine : lds, sub, s); // every lane takes part (DPP combine); non-live lanes read game 0 of the block
     const bool active = live && !frozen;
@@ -412,7 +454,14 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
     if (active) {
         if (term) {
             if (c.autoreset) { // reset(seed = next_seed) + setup_game (envs/ewn.py:488-494, 94-108)
-                r.next_episode(B.rng, c.N, game, c.seed_stride, c.key);
+                LaneRng::Pending pend; pend.n = 0; pend.slot0 = pend.slot1 = pend.seed0 = pend.seed1 = 0;
+                r.next_episode(B.rng, c.N, game, c.seed_stride, c.key, (RNGK == 0 && B.mtq) ? &pend : nullptr);
+                if constexpr (RNGK == 0) {
+                    if (B.mtq && writer) { // park the refill requests in LDS; the block moves them to its list region below
+                        if (pend.n >= 1u) ((uint4 *)(qlds + 4))[atomicAdd(&qlds[0], 1u)] = make_uint4((u32)game | (pend.slot0 << 30), pend.seed0, epoch, 0u);
+                        if (pend.n >= 2u) ((uint4 *)(qlds + 4))[atomicAdd(&qlds[0], 1u)] = make_uint4((u32)game | (pend.slot1 << 30), pend.seed1, epoch, 0u);
+                    }
+                }
                 d3_init_state<S>(Tb, s);
                 dice = r.first_dice(6);
             }
@@ -454,4 +503,13 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
     __syncthreads();
     block_copy_out(B.board + (size_t)g0 * CELLS, lds, ng * CELLS);
     if (B.tboard) block_copy_out(B.tboard + (size_t)g0 * CELLS, lds_t, ng * CELLS);
+    if constexpr (RNGK == 0) {
+        if (B.mtq) { // this block's parked requests -> its own region of this launch's list; the count is a plain store
+            const int sb = (int)blockIdx.x - c.refill_blocks;
+            const u32 nq = min(qlds[0], (u32)Q.per_blk);
+            uint4 *list = Q.list + ((size_t)phase * Q.nblk + sb) * Q.per_blk;
+            for (u32 i = threadIdx.x; i < nq; i += blockDim.x) list[i] = ((const uint4 *)(qlds + 4))[i];
+            if (threadIdx.x == 0) Q.cnt[(size_t)phase * Q.nb4 + sb] = nq;
+        }
+    }
 }

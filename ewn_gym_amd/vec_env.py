@@ -133,7 +133,7 @@ class VecEWN:
 
     def state_dict(self):
         """Checkpoint of the env (the reference never checkpoints env state)."""
-        keys = ("board", "dice", "done", "rng_state", "prev_score", "tolerance")
+        keys = ("board", "dice", "done", "rng_state", "scratch", "prev_score", "tolerance")  # scratch: the MT refill queue
         return {k: getattr(self, k).clone() for k in keys if getattr(self, k) is not None}
 
     def load_state_dict(self, sd):

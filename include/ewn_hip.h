@@ -103,7 +103,8 @@ typedef struct ewn_state {
     int8_t *dice;        /* [N]       the observation "dice_roll" */
     uint8_t *done;       /* [N]       1 = terminated and not yet reset (lane frozen) */
     uint32_t *rng;       /* N*ewn_rng_words() words: [N][4] headers {seed, draw index, next_seed, flags}, then (MT kind)
-                            [N][2][W] windows of precomputed MT19937 outputs (this episode's and the next one's) */
+                            [N][3][W] windows of precomputed MT19937 outputs (this episode's and the next two) and
+                            [N] reset epochs.  Opaque to the caller; zero-initialise, then ewn_init_aux. */
     double *prev_score;  /* [N]  shaped env only (training_ewn.py:35), may be NULL otherwise */
     int32_t *tolerance;  /* [N]  shaped env only (training_ewn.py:38), may be NULL otherwise */
     const void *tables;  /* device copy of ewn_build_tables() output, or NULL.  When present and the config is
@@ -131,7 +132,9 @@ const char *ewn_strerror(int code);
 
 /* number of uint32 words per lane in ewn_state.rng for this config (<0 on error) */
 int ewn_rng_words(const ewn_config *cfg);
-/* bytes of device scratch ewn_step needs for this config (0 if none; <0 on error): the MCTS split-phase buffers */
+/* bytes of device scratch ewn_step needs for this config (0 if none; <0 on error): the MCTS split-phase buffers, or
+ * (MT kind with auto-reset) the queue through which one step launch hands window refills to the next.  The scratch
+ * must be zero-initialised once and then left alone between calls. */
 int64_t ewn_step_scratch_bytes(const ewn_config *cfg);
 
 /* Search tables of the specialised depth-3 kernel (leaf-value ranks, ring-order geometry;

@@ -38,9 +38,9 @@ def test_struct_layout_matches_header():
 
 def test_config_validation_on_host():
     lib = _lib.load()
-    assert lib.ewn_rng_words(C.byref(cfg())) == 4 + 2 * 128   # header + current and next episode's MT windows
+    assert lib.ewn_rng_words(C.byref(cfg())) == 4 + 3 * 128 + 1   # header + three rotating MT windows + reset epoch
     assert lib.ewn_rng_words(C.byref(cfg(rng_kind=1))) == 4
-    assert lib.ewn_rng_words(C.byref(cfg(mt_window=227))) == 4 + 2 * 227
+    assert lib.ewn_rng_words(C.byref(cfg(mt_window=227))) == 4 + 3 * 227 + 1
     assert lib.ewn_rng_words(C.byref(cfg(mt_window=228))) == -1
     assert lib.ewn_rng_words(C.byref(cfg(cube_layer=4))) == -1            # assert cube_layer < board_size - 1 (envs/ewn.py:47)
     assert lib.ewn_rng_words(C.byref(cfg(board_size=9, cube_layer=3))) == -4  # valid upstream, > 64-bit mask here
@@ -51,7 +51,9 @@ def test_config_validation_on_host():
     assert lib.ewn_rng_words(None) == -2
     assert lib.ewn_step_scratch_bytes(C.byref(cfg())) == 0
     assert lib.ewn_step_scratch_bytes(C.byref(cfg(opponent_kind=2))) == 64 * (4 + 4 + 24 + 25)
-    assert lib.ewn_step_scratch_bytes(C.byref(cfg(autoreset=1))) == 0
+    # MT kind with auto-reset: phase word + 2 x per-block counts + 2 x per-block request regions (64 lanes = 1 block of 64 games)
+    assert lib.ewn_step_scratch_bytes(C.byref(cfg(autoreset=1))) == 16 + 2 * 4 * 4 + 2 * 1 * 128 * 16
+    assert lib.ewn_step_scratch_bytes(C.byref(cfg(autoreset=1, rng_kind=1))) == 0
 
 
 def test_null_pointers_are_rejected_before_any_launch():

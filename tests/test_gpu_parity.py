@@ -273,6 +273,43 @@ def test_fused_random_agent_output(ea, kw):
         assert ok.all()
 
 
+@pytest.mark.parametrize("use_tables", [True, False])
+def test_mt_window_rotation_survives_starvation_and_checkpoint(ea, use_tables):
+    """MT kind: (a) wipe every lane's READY/X/Y bookkeeping so the next auto-resets find no prepared window (the
+    rebuild-in-place path), (b) checkpoint / restore mid-run -- dice must keep matching the oracle's numpy stream."""
+    N = 1024
+    env = ea.VecEWN(N, opponent_policy="minimax", max_depth=3, rng="mt19937", autoreset=True, use_tables=use_tables)
+    orc = po.OracleVecEnv(N, opponent="minimax", max_depth=3, rng="mt19937", autoreset=True)
+    seeds = np.arange(N, dtype=np.uint32) * 3 + 11
+    env.reset(seeds=seeds)
+    orc.reset(seeds=seeds)
+    sd = None
+    for t in range(40):
+        if t == 6:
+            env.rng_state.view(-1)[3:4 * N:4] &= 0x31          # keep overflow bit + current slot, drop READY / X / Y
+        if t == 15:
+            sd = env.state_dict()
+            saved_orc_step = t
+        a = orc.sample_legal_actions(t)
+        res = [cpu(x) for x in env.step(a)]
+        ores = orc.step(a)
+        for x, o in zip(res, ores):
+            assert np.array_equal(x, o), t
+    # restore the checkpoint into a fresh engine and replay the same steps against a fresh oracle run
+    env2 = ea.VecEWN(N, opponent_policy="minimax", max_depth=3, rng="mt19937", autoreset=True, use_tables=use_tables)
+    env2.load_state_dict(sd)
+    orc2 = po.OracleVecEnv(N, opponent="minimax", max_depth=3, rng="mt19937", autoreset=True)
+    orc2.reset(seeds=seeds)
+    for t in range(saved_orc_step):
+        orc2.step(orc2.sample_legal_actions(t))
+    for t in range(saved_orc_step, 40):
+        a = orc2.sample_legal_actions(t)
+        res = [cpu(x) for x in env2.step(a)]
+        ores = orc2.step(a)
+        for x, o in zip(res, ores):
+            assert np.array_equal(x, o), t
+
+
 def test_frozen_lanes_without_autoreset(ea):
     N = 512
     env = ea.VecEWN(N, rng="mt19937")

@@ -2,7 +2,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, ewn_gym_amd as ea
 N = 65536
-env = ea.VecEWN(N, opponent_policy="minimax", max_depth=3, rng=sys.argv[1] if len(sys.argv) > 1 else "philox", autoreset=True, philox_key=2024)
+env = ea.VecEWN(N, opponent_policy="minimax", max_depth=3, rng=sys.argv[1] if len(sys.argv) > 1 else "philox", autoreset=True, philox_key=2024, want_terminal_obs=False)
 env.reset(seeds=np.arange(N) + 9487)
 acts = torch.zeros((N, 2), dtype=torch.int8, device="cuda")
 for t in range(30):
@@ -15,8 +15,11 @@ env.sample_legal_actions(31, out=acts)
 env.step(acts)
 torch.cuda.synchronize()
 T = int(os.environ.get("EWN_D3_T", "4"))
-nb = N * T // 256
+nb = N * T // 256 + (256 if (len(sys.argv) > 1 and sys.argv[1] == 'mt19937') else 0)
 st = dbg[:nb * 64].view(torch.int64).cpu().numpy().reshape(nb, 8)
+if len(sys.argv) > 1 and sys.argv[1] == 'mt19937':
+    st = st[256:]   # the first 256 blocks of the MT launch are refill blocks
+    nb -= 256
 order = [0, 1, 2, 7, 3, 4, 5, 6]
 st = st[:, order]
 d = np.diff(st, axis=1)
