@@ -382,8 +382,27 @@ __global__ __launch_bounds__(BS) void k_legal(Geom g, int M, const int8_t *board
     if (n_acts) n_acts[m] = (int8_t)n;
 }
 
-template <int SIDE, int NW> EWN_DEV void rollout_ply(const Geom &g, GState<NW> &s, PhiloxStream &ps);
-EWN_DEV int ps_below(PhiloxStream &ps, int n);
+// A playout's randomness: ONE Philox block keyed by (observation, playout, tag) seeds a 32-bit counter generator
+// (splitmix-style finaliser: 2 multiplies per draw instead of Philox's 40 per four words).  A playout makes ~70 draws
+// (dice + pick per ply); the reference uses an unseeded Python `random` here, so parity is statistical either way.
+struct PlayoutRng {
+    u32 s;
+    EWN_DEV void init(u32 c1, u32 c2, u32 c3, u64 key)
+    {
+        u32 o[4];
+        philox4x32_10(0u, c1, c2, c3, (u32)key, (u32)(key >> 32), o);
+        s = o[0];
+    }
+    EWN_DEV u32 next()
+    {
+        u32 z = (s += 0x9E3779B9u);
+        z ^= z >> 16; z *= 0x21f0aaadu; z ^= z >> 15; z *= 0x735a2d97u; z ^= z >> 15;
+        return z;
+    }
+};
+
+template <int SIDE, int NW> EWN_DEV void rollout_ply(const Geom &g, GState<NW> &s, PlayoutRng &ps);
+EWN_DEV int ps_below(PlayoutRng &ps, int n);
 
 template <int NW>
 __global__ __launch_bounds__(BS) void k_apply_action(Geom g, int M, const int8_t *boards, const int8_t *dice, int player,
@@ -415,8 +434,8 @@ __global__ __launch_bounds__(BS) void k_playout_wins(Geom g, int M, int n_sims, 
     const int m = (int)(idx / n_sims), r = (int)(idx % n_sims);
     GState<NW> s;
     decode_board<NW>(g, boards + (size_t)m * g.cells, s);
-    PhiloxStream ps;
-    ps.init((u32)m, (u32)r, 0x53494D55u, key, 0u);
+    PlayoutRng ps;
+    ps.init((u32)m, (u32)r, 0x53494D55u, key);
     int cur = first_player == 1 ? 0 : 1;
     for (int ply = 0; ply < 1024 && !is_win<NW>(g, s); ply++) {
         if (cur == 0) rollout_ply<0, NW>(g, s, ps); else rollout_ply<1, NW>(g, s, ps);
@@ -519,7 +538,7 @@ __global__ __launch_bounds__(BS) void k_mcts_init(Geom g, int M, const int8_t *b
     for (int i = 0; i < 6; i++) wins[(size_t)m * 6 + i] = i < n ? 0 : -1;
 }
 
-EWN_DEV int ps_below(PhiloxStream &ps, int n)
+EWN_DEV int ps_below(PlayoutRng &ps, int n)
 {
     if (n <= 1) return 0;
     const u32 rng = (u32)(n - 1);
@@ -534,7 +553,7 @@ EWN_DEV int ps_below(PhiloxStream &ps, int n)
 // One uniformly random legal move of SIDE (classical_policies/mcts.py:29-35): dice, legal list in the reference's
 // order as a 6-bit mask (larger-neighbour cube's dirs, then smaller-neighbour cube's), uniform pick, apply.
 template <int SIDE, int NW>
-EWN_DEV void rollout_ply(const Geom &g, GState<NW> &s, PhiloxStream &ps)
+EWN_DEV void rollout_ply(const Geom &g, GState<NW> &s, PlayoutRng &ps)
 {
     const int d = 1 + ps_below(ps, 6); // random.randint(1, 6), mcts.py:29
     const CubeSel cs = select_cubes(alive_of<SIDE>(s), d);
@@ -584,14 +603,14 @@ __global__ __launch_bounds__(BS) void k_mcts_rollout(Geom g, int M, int total, c
     int r = c * MCTS_RPT, w = 0, cur = 1, plies = 0;
     const int r1 = min(r + MCTS_RPT, total);
     GState<NW> s = base;
-    PhiloxStream ps;
-    ps.init(id, (u32)(i * total + r), 0x4D435453u, key, 0u);
+    PlayoutRng ps;
+    ps.init(id, (u32)(i * total + r), 0x4D435453u, key);
     for (int it = 0; it < MCTS_RPT * 1100 && r < r1; it++) {
         if (is_win<NW>(g, s) || plies >= 1024) {
             w += ((s.occP & g.corner_br) || s.occN == 0) ? 1 : 0; // mcts.py:39-41
             r++;
             s = base; cur = 1; plies = 0; // BOTTOM_RIGHT replies first, mcts.py:26
-            ps.init(id, (u32)(i * total + r), 0x4D435453u, key, 0u);
+            ps.init(id, (u32)(i * total + r), 0x4D435453u, key);
         } else {
             if (cur == 0) rollout_ply<0, NW>(g, s, ps); else rollout_ply<1, NW>(g, s, ps);
             cur ^= 1; plies++;
