@@ -1,4 +1,5 @@
-// ewn_fast.hpp -- the specialised depth-3 'hybrid' expectiminimax (the headline path).
+// ewn_fast.hpp -- search tables of the specialised depth-3 'hybrid' expectiminimax (built on the host by
+// build_fast_tables, read from LDS by d3_search in ewn_step_d3.hpp) and the reasoning behind them.
 //
 // What classical_policies/minimax.py:19-73 computes at max_depth=3:
 //   for each root move a_i (<= 6, reference order):   B1 = apply(B, a_i)
@@ -20,9 +21,10 @@
 //    identical outcome, and w_d/6 is a table read of the host-computed quotient;
 //  * the <= 216 leaves collapse to <= 108 distinct positions (a reply is a (cube, dir)
 //    pair; which two cubes a dice value selects only decides which of those are scanned);
-//  * the reference's early exit "w <= alpha" is replayed in closed form: the reply list is
-//    scanned in order as prefix minima m_1 >= m_2 >= ...; the loop's result is the first
-//    m_j <= alpha, else the last one  ==  max(last, max_j (m_j <= alpha ? m_j : lowest)).
+//  * the reference's early exit "w <= alpha" is replayed in closed form: along a cube's replies
+//    the running minimum is non-increasing, so the loop stops at the LARGEST prefix minimum
+//    that is <= alpha (`cut`, 0 if none); for the (larger-neighbour F, smaller-neighbour G)
+//    cube pair a dice selects the result is  cutF ? cutF : cutG ? cutG : min(p2F, p2G).
 #pragma once
 #include "ewn_core.hpp"
 

@@ -1,11 +1,12 @@
-// ewn_kernels.hip -- gfx950 kernels and the C ABI (include/ewn_hip.h) of libewn_hip.so.
+// ewn_kernels.hip -- the generic gfx950 kernels (every board size / cube layer / opponent / depth / heuristic /
+// reward shaping), the stateless policy and rule queries, and the C ABI (include/ewn_hip.h) of libewn_hip.so.
+// The headline kernel (depth-3 'hybrid' or random opponent, cube_layer 3) lives in ewn_step_d3.hpp.
 //
-// Layout in HBM: board int8 [N][S*S] (one contiguous row per lane, so a block of 256
-// lanes is one contiguous 6.4 KB (5x5) / 12.5 KB (7x7) span that is copied to and
-// from LDS with coalesced dword accesses), dice int8 [N], done u8 [N], rng u32
-// [N][4 + W].  One thread owns one lane (game); the wavefront is the unit of
-// scheduling, not the unit of work -- a 25-cell board would leave 39 of 64 lanes
-// idle if a whole wavefront served one game.
+// Layout in HBM: board int8 [N][S*S] (one contiguous row per lane, so a block of 256 lanes is one contiguous
+// 6.4 KB (5x5) / 12.5 KB (7x7) span copied to and from LDS in coalesced 16-byte pieces), dice int8 [N], done u8 [N],
+// rng u32 (headers [N][4], then for the MT kind windows [N][3][W] and epochs [N]).  In these generic kernels one thread
+// owns one lane (game); the wavefront is the unit of scheduling, not the unit of work -- a 25-cell board would leave
+// 39 of 64 lanes idle if a whole wavefront served one game.
 #include "ewn_core.hpp"
 #include "ewn_fast.hpp"
 #include "../../include/ewn_hip.h"
