@@ -59,8 +59,11 @@ class ActorCritic(nn.Module):
         if deterministic:
             a0, a1 = l0.argmax(1), l1.argmax(1)
         else:
-            a0 = torch.multinomial(torch.softmax(l0, 1), 1, generator=generator).squeeze(1)
-            a1 = torch.multinomial(torch.softmax(l1, 1), 1, generator=generator).squeeze(1)
+            # Gumbel-max: argmax(logits - log(-log u)) ~ Categorical(softmax(logits)); one rand call, no sync,
+            # capturable in a hipGraph (torch.multinomial is not)
+            u = torch.rand(l0.shape[0], 5, device=l0.device, generator=generator).clamp_(1e-20, 1.0)
+            g = -torch.log(-torch.log(u))
+            a0, a1 = (l0 + g[:, :2]).argmax(1), (l1 + g[:, 2:]).argmax(1)
         return torch.stack([a0, a1], 1).to(torch.int8), value
 
     def evaluate_actions(self, board, dice, actions):
@@ -104,7 +107,7 @@ def all_reduce_gradients(params, world_size=None):
 
 class A2CTrainer:
     def __init__(self, env, n_steps=5, learning_rate=7e-4, gamma=0.99, gae_lambda=1.0, ent_coef=0.0, vf_coef=0.5,
-                 max_grad_norm=0.5, seed=None, hidden=64, device=None):
+                 max_grad_norm=0.5, seed=None, hidden=64, device=None, use_graph=True):
         self.env = env
         self.device = torch.device(device) if device is not None else env.board.device
         if seed is not None:
@@ -118,6 +121,30 @@ class A2CTrainer:
         if seed is not None:
             self.gen.manual_seed(seed + 7919 * getattr(env, "lane_offset", 0))
         self.num_timesteps = 0
+        # rollout storage, allocated once: [T, N, ...]
+        T, N, S = n_steps, env.N, env.S
+        dev = self.device
+        self._boards = torch.zeros((T, N, S, S), dtype=torch.int8, device=dev)
+        self._dices = torch.zeros((T, N), dtype=torch.int8, device=dev)
+        self._acts = torch.zeros((T, N, 2), dtype=torch.int8, device=dev)
+        self._vals = torch.zeros((T, N), dtype=torch.float32, device=dev)
+        self._rews = torch.zeros((T, N), dtype=torch.float32, device=dev)
+        self._dones = torch.zeros((T, N), dtype=torch.float32, device=dev)
+        self._graph = None
+        self.use_graph = use_graph and self.device.type == "cuda"
+
+    def _rollout(self):
+        """n_steps of (observe, act, env.step) into the preallocated buffers; no host sync, no allocation that outlives it"""
+        env = self.env
+        for t in range(self.n_steps):
+            self._boards[t].copy_(env.board)
+            self._dices[t].copy_(env.dice)
+            a, v = self.model.act(env.board, env.dice)
+            self._acts[t].copy_(a)
+            self._vals[t].copy_(v)
+            _, _, r, term, _, _ = env.step(self._acts[t])
+            self._rews[t].copy_(r)
+            self._dones[t].copy_(term)
 
     def _sync_parameters(self):
         import torch.distributed as dist
@@ -127,18 +154,27 @@ class A2CTrainer:
 
     def collect_and_update(self):
         env, T, N = self.env, self.n_steps, self.env.N
-        boards, dices, acts, rews, dones, vals = [], [], [], [], [], []
-        for _ in range(T):
-            b, d = env.board.clone(), env.dice.clone()
-            a, v = self.model.act(b, d, generator=self.gen)
-            _, _, r, term, _, _ = env.step(a)
-            boards.append(b); dices.append(d); acts.append(a); vals.append(v)
-            rews.append(r.to(torch.float32)); dones.append((term != 0).to(torch.float32))
+        if self.use_graph:
+            # the whole n-step rollout (policy forward, sampling, ewn_step, bookkeeping) is one captured hipGraph: the
+            # policy net is ~13 k parameters, so un-captured the loop is pure launch overhead (~25 tiny kernels per step)
+            if self._graph is None:
+                torch.cuda.synchronize()
+                side = torch.cuda.Stream()
+                with torch.cuda.stream(side):
+                    self._rollout()          # warm-up outside capture (lazy inits)
+                side.synchronize()
+                self._graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph):
+                    self._rollout()
+            self._graph.replay()
+        else:
+            self._rollout()
         with torch.no_grad():
             _, _, last_value = self.model(env.board, env.dice)
-        rews, dones, vals = torch.stack(rews), torch.stack(dones), torch.stack(vals)
+        rews, dones, vals = self._rews, self._dones, self._vals
         adv, ret = n_step_returns(rews, vals, dones, last_value, self.gamma, self.gae_lambda)
-        logp, ent, value = self.model.evaluate_actions(torch.cat(boards), torch.cat(dices), torch.cat(acts))
+        logp, ent, value = self.model.evaluate_actions(self._boards.reshape(T * N, env.S, env.S), self._dices.reshape(T * N),
+                                                       self._acts.reshape(T * N, 2))
         policy_loss = -(adv.reshape(-1) * logp).mean()
         value_loss = torch.nn.functional.mse_loss(ret.reshape(-1), value)
         entropy_loss = -ent.mean()
@@ -149,16 +185,19 @@ class A2CTrainer:
         nn.utils.clip_grad_norm_(self.model.parameters(), self.max_grad_norm)
         self.opt.step()
         self.num_timesteps += T * N
-        return {"loss": float(loss.item()), "policy_loss": float(policy_loss.item()), "value_loss": float(value_loss.item()),
-                "entropy": float(-entropy_loss.item()), "mean_reward": float(rews.mean().item()),
-                "episodes": int(dones.sum().item())}
+        stats = torch.stack([loss.detach(), policy_loss.detach(), value_loss.detach(), -entropy_loss.detach(), rews.mean(), dones.sum()])
+        self._last_stats = stats   # read lazily: a .item() here would stall the stream every update
+        return stats
+
+    def stats_dict(self, stats=None):
+        s = (self._last_stats if stats is None else stats).tolist()
+        return {"loss": s[0], "policy_loss": s[1], "value_loss": s[2], "entropy": s[3], "mean_reward": s[4], "episodes": int(s[5])}
 
     def learn(self, total_timesteps):
-        stats = None
         target = self.num_timesteps + total_timesteps
         while self.num_timesteps < target:
-            stats = self.collect_and_update()
-        return stats
+            self.collect_and_update()
+        return self.stats_dict()
 
     def policy_fn(self, deterministic=True):
         """A batched policy for tournament.evaluate / hand-rolled loops: (board, dice, t) -> int8 [N,2]"""

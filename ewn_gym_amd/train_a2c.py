@@ -56,7 +56,7 @@ def main():
     trainer = A2CTrainer(env, n_steps=a.n_steps, learning_rate=a.learning_rate, seed=a.seed)
     best = -1.0
     for epoch in range(a.epoch_num):
-        stats = trainer.learn(a.timesteps_per_epoch // world)
+        stats = trainer.learn(a.timesteps_per_epoch // world)   # dict of the last update's statistics
         # train.py:73-81: evaluate on the UN-shaped env against minimax(depth 5), seeds 0..n-1, deterministic actions
         n_eval = a.eval_episode_num // world
         r = evaluate(trainer.policy_fn(True), {"kind": "minimax", "max_depth": a.eval_max_depth}, num=n_eval,

@@ -71,6 +71,7 @@ def test_a2c_learns_to_avoid_illegal_moves():
     for _ in range(300):
         stats = tr.collect_and_update()
     after = illegal_rate()
+    stats = tr.stats_dict(stats)
     assert all(np.isfinite(v) for v in stats.values())
     assert any(not torch.equal(a, b) for a, b in zip(p0, tr.model.parameters()))
     assert tr.num_timesteps == 300 * 5 * N

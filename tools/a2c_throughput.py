@@ -15,4 +15,4 @@ for N in (4096, 65536):
     for _ in range(40):
         st = tr.collect_and_update()
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print("A2C N=%d: %.3e env steps/s (%.2f ms per 5-step update), mean reward %.3f" % (N, (tr.num_timesteps - n0) / dt, dt / 40 * 1e3, st["mean_reward"]), flush=True)
+    print("A2C N=%d: %.3e env steps/s (%.2f ms per 5-step update), mean reward %.3f" % (N, (tr.num_timesteps - n0) / dt, dt / 40 * 1e3, tr.stats_dict(st)["mean_reward"]), flush=True)
