@@ -9,6 +9,7 @@
 // 39 of 64 lanes idle if a whole wavefront served one game.
 #include "ewn_core.hpp"
 #include "ewn_fast.hpp"
+#include "ewn_playout.hpp"
 #include "../../include/ewn_hip.h"
 #include <cstdlib>
 
@@ -383,27 +384,7 @@ __global__ __launch_bounds__(BS) void k_legal(Geom g, int M, const int8_t *board
     if (n_acts) n_acts[m] = (int8_t)n;
 }
 
-// A playout's randomness: ONE Philox block keyed by (observation, playout, tag) seeds a 32-bit counter generator
-// (splitmix-style finaliser: 2 multiplies per draw instead of Philox's 40 per four words).  A playout makes ~70 draws
-// (dice + pick per ply); the reference uses an unseeded Python `random` here, so parity is statistical either way.
-struct PlayoutRng {
-    u32 s;
-    EWN_DEV void init(u32 c1, u32 c2, u32 c3, u64 key)
-    {
-        u32 o[4];
-        philox4x32_10(0u, c1, c2, c3, (u32)key, (u32)(key >> 32), o);
-        s = o[0];
-    }
-    EWN_DEV u32 next()
-    {
-        u32 z = (s += 0x9E3779B9u);
-        z ^= z >> 16; z *= 0x21f0aaadu; z ^= z >> 15; z *= 0x735a2d97u; z ^= z >> 15;
-        return z;
-    }
-};
-
 template <int SIDE, int NW> EWN_DEV void rollout_ply(const Geom &g, GState<NW> &s, PlayoutRng &ps);
-EWN_DEV int ps_below(PlayoutRng &ps, int n);
 
 template <int NW>
 __global__ __launch_bounds__(BS) void k_apply_action(Geom g, int M, const int8_t *boards, const int8_t *dice, int player,
@@ -425,7 +406,7 @@ __global__ __launch_bounds__(BS) void k_apply_action(Geom g, int M, const int8_t
     if (valid) valid[m] = ok ? 1 : 0;
 }
 
-// MinimaxEnv.simulate, envs/minimax_ewn.py:215-238: one thread per (position, playout)
+// MinimaxEnv.simulate, envs/minimax_ewn.py:215-238: one thread per (position, playout); any cube_layer
 template <int NW>
 __global__ __launch_bounds__(BS) void k_playout_wins(Geom g, int M, int n_sims, const int8_t *boards, int first_player, u64 key,
                                                      int32_t *wins)
@@ -436,13 +417,36 @@ __global__ __launch_bounds__(BS) void k_playout_wins(Geom g, int M, int n_sims, 
     GState<NW> s;
     decode_board<NW>(g, boards + (size_t)m * g.cells, s);
     PlayoutRng ps;
-    ps.init((u32)m, (u32)r, 0x53494D55u, key);
+    ps.seed(PlayoutRng::chunk_word((u32)m, (u32)(r - r % PLAYOUT_CHAIN), 0x53494D55u, key), (u32)(r % PLAYOUT_CHAIN));
     int cur = first_player == 1 ? 0 : 1;
     for (int ply = 0; ply < 1024 && !is_win<NW>(g, s); ply++) {
         if (cur == 0) rollout_ply<0, NW>(g, s, ps); else rollout_ply<1, NW>(g, s, ps);
         cur ^= 1;
     }
     if ((s.occP & g.corner_br) || s.occN == 0) atomicAdd(&wins[m], 1);
+}
+
+// the same for cube_layer <= 3: one thread per (position, chunk of PLAYOUT_CHAIN playouts), ewn_playout.hpp
+__global__ __launch_bounds__(BS) void k_playout_wins_lean(Geom g, int M, int n_sims, const int8_t *boards, int first_player, u64 key,
+                                                          int32_t *wins)
+{
+    __shared__ PlayTab T;
+    playtab_build(&T, g.S);
+    __syncthreads();
+    const int chunks = (n_sims + PLAYOUT_CHAIN - 1) / PLAYOUT_CHAIN;
+    const long long idx = (long long)blockIdx.x * BS + threadIdx.x;
+    if (idx >= (long long)M * chunks) return;
+    const int m = (int)(idx / chunks), r0 = (int)(idx % chunks) * PLAYOUT_CHAIN, nj = min(PLAYOUT_CHAIN, n_sims - r0);
+    GState<1> s;
+    decode_board<1>(g, boards + (size_t)m * g.cells, s);
+    int w;
+    if (is_win<1>(g, s)) w = ((s.occP & g.corner_br) || s.occN == 0) ? nj : 0;
+    else {
+        const PState b0 = pstate_from(g, s);
+        const u32 word = PlayoutRng::chunk_word((u32)m, (u32)r0, 0x53494D55u, key);
+        w = first_player == 1 ? run_playouts<0>(&T, b0, g.S, word, nj) : run_playouts<1>(&T, b0, g.S, word, nj);
+    }
+    if (w) atomicAdd(&wins[m], w);
 }
 
 template <int NW>
@@ -539,24 +543,14 @@ __global__ __launch_bounds__(BS) void k_mcts_init(Geom g, int M, const int8_t *b
     for (int i = 0; i < 6; i++) wins[(size_t)m * 6 + i] = i < n ? 0 : -1;
 }
 
-EWN_DEV int ps_below(PlayoutRng &ps, int n)
-{
-    if (n <= 1) return 0;
-    const u32 rng = (u32)(n - 1);
-    u32 mask = rng;
-    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4;
-    u32 v;
-    int guard = 0;
-    do { v = ps.next() & mask; } while (v > rng && ++guard < 4096);
-    return (int)(v > rng ? 0u : v);
-}
-
 // One uniformly random legal move of SIDE (classical_policies/mcts.py:29-35): dice, legal list in the reference's
 // order as a 6-bit mask (larger-neighbour cube's dirs, then smaller-neighbour cube's), uniform pick, apply.
 template <int SIDE, int NW>
 EWN_DEV void rollout_ply(const Geom &g, GState<NW> &s, PlayoutRng &ps)
 {
-    const int d = 1 + ps_below(ps, 6); // random.randint(1, 6), mcts.py:29
+    u32 d0, frac;
+    ps.draw(d0, frac);
+    const int d = 1 + (int)d0; // random.randint(1, 6), mcts.py:29
     const CubeSel cs = select_cubes(alive_of<SIDE>(s), d);
     const bool have0 = cs.exact || cs.has_up, have1 = !cs.exact && cs.has_down;
     const int k0 = cs.exact ? cs.k_exact : cs.k_up, k1 = cs.k_down;
@@ -568,55 +562,67 @@ EWN_DEV void rollout_ply(const Geom &g, GState<NW> &s, PlayoutRng &ps)
         okm |= ((have1 && dir_ok<SIDE>(g, p1, dir)) ? 1u : 0u) << (3 + dir);
     }
     const int n = __popc(okm);
-    const int pick = ps_below(ps, n);
+    const int pick = (int)PlayoutRng::pick(frac, (u32)n);
     u32 m = okm;
     for (int i = 0; i < pick; i++) m &= m - 1;
     const int slot = __ffs((int)m) - 1;
     if (n > 0) apply_move<SIDE, NW>(g, s, slot < 3 ? k0 : k1, slot < 3 ? slot : slot - 3);
 }
 
-// playouts per thread.  Measured on MI355X (7x7, 400 playouts per root move, 32 768 lanes): 1 -> 27.8 ms/step,
-// 2 -> 37.9, 4 -> 42.9, 8 -> 48.0: chaining playouts in a lane does not pay, finished waves are replaced fast enough.
-#ifndef MCTS_RPT
-#define MCTS_RPT 1
-#endif
-
-// classical_policies/mcts.py:21-45: thread (observation m, root move i, chunk c) plays playouts c*RPT .. c*RPT+RPT-1 of that
-// root move back to back.  Playout r always uses the Philox stream (obs_id, i*total + r), whatever thread runs it.
+// classical_policies/mcts.py:21-45, any cube_layer: thread (observation m, root move i, playout r)
 template <int NW>
 __global__ __launch_bounds__(BS) void k_mcts_rollout(Geom g, int M, int total, const int8_t *boards, const int8_t *dice,
                                                      const u32 *obs_id, u64 key, int32_t *wins)
 {
-    const int chunks = (total + MCTS_RPT - 1) / MCTS_RPT;
+    const long long idx = (long long)blockIdx.x * BS + threadIdx.x;
+    const long long per = 6ll * total;
+    if (idx >= (long long)M * per) return;
+    const int m = (int)(idx / per), rem = (int)(idx % per), i = rem / total, r = rem % total;
+    if (wins[(size_t)m * 6 + i] < 0) return; // no such root move (or inactive lane); set by k_mcts_init, never by this kernel
+    GState<NW> s;
+    decode_board<NW>(g, boards + (size_t)m * g.cells, s);
+    {
+        int j = 0, mk = 0, md = 0;
+        for_each_legal<0, NW>(g, s, dice[m], [&](int, int k, int dir) { if (j == i) { mk = k; md = dir; } j++; return j <= i; });
+        apply_move<0, NW>(g, s, mk, md);
+    }
+    PlayoutRng ps;
+    ps.seed(PlayoutRng::chunk_word(obs_id ? obs_id[m] : (u32)m, (u32)(i * total + r - r % PLAYOUT_CHAIN), 0x4D435453u, key),
+            (u32)(r % PLAYOUT_CHAIN));
+    int cur = 1; // BOTTOM_RIGHT replies first, mcts.py:26
+    for (int ply = 0; ply < 1024 && !is_win<NW>(g, s); ply++) {
+        if (cur == 0) rollout_ply<0, NW>(g, s, ps); else rollout_ply<1, NW>(g, s, ps);
+        cur ^= 1;
+    }
+    if ((s.occP & g.corner_br) || s.occN == 0) atomicAdd(&wins[(size_t)m * 6 + i], 1); // mcts.py:39-41
+}
+
+// the same for cube_layer <= 3: thread (observation m, root move i, chunk c) plays playouts c*PLAYOUT_CHAIN .. of that
+// root move back to back (ewn_playout.hpp).  Consecutive threads share (m, i): one base position per wave, broadcast loads.
+__global__ __launch_bounds__(BS) void k_mcts_rollout_lean(Geom g, int M, int total, const int8_t *boards, const int8_t *dice,
+                                                          const u32 *obs_id, u64 key, int32_t *wins)
+{
+    __shared__ PlayTab T;
+    playtab_build(&T, g.S);
+    __syncthreads();
+    const int chunks = (total + PLAYOUT_CHAIN - 1) / PLAYOUT_CHAIN;
     const long long idx = (long long)blockIdx.x * BS + threadIdx.x;
     const long long per = 6ll * chunks;
     if (idx >= (long long)M * per) return;
-    const int m = (int)(idx / per), rem = (int)(idx % per), i = rem / chunks, c = rem % chunks;
-    if (wins[(size_t)m * 6 + i] < 0) return; // no such root move (or inactive lane); set by k_mcts_init, never by this kernel
-    GState<NW> base;
-    decode_board<NW>(g, boards + (size_t)m * g.cells, base);
+    const int m = (int)(idx / per), rem = (int)(idx % per), i = rem / chunks, r0 = (rem % chunks) * PLAYOUT_CHAIN;
+    if (wins[(size_t)m * 6 + i] < 0) return;
+    const int nj = min(PLAYOUT_CHAIN, total - r0);
+    GState<1> s;
+    decode_board<1>(g, boards + (size_t)m * g.cells, s);
     {
         int j = 0, mk = 0, md = 0;
-        for_each_legal<0, NW>(g, base, dice[m], [&](int, int k, int dir) { if (j == i) { mk = k; md = dir; } j++; return j <= i; });
-        apply_move<0, NW>(g, base, mk, md);
+        for_each_legal<0, 1>(g, s, dice[m], [&](int, int k, int dir) { if (j == i) { mk = k; md = dir; } j++; return j <= i; });
+        apply_move<0, 1>(g, s, mk, md);
     }
-    const u32 id = obs_id ? obs_id[m] : (u32)m;
-    int r = c * MCTS_RPT, w = 0, cur = 1, plies = 0;
-    const int r1 = min(r + MCTS_RPT, total);
-    GState<NW> s = base;
-    PlayoutRng ps;
-    ps.init(id, (u32)(i * total + r), 0x4D435453u, key);
-    for (int it = 0; it < MCTS_RPT * 1100 && r < r1; it++) {
-        if (is_win<NW>(g, s) || plies >= 1024) {
-            w += ((s.occP & g.corner_br) || s.occN == 0) ? 1 : 0; // mcts.py:39-41
-            r++;
-            s = base; cur = 1; plies = 0; // BOTTOM_RIGHT replies first, mcts.py:26
-            ps.init(id, (u32)(i * total + r), 0x4D435453u, key);
-        } else {
-            if (cur == 0) rollout_ply<0, NW>(g, s, ps); else rollout_ply<1, NW>(g, s, ps);
-            cur ^= 1; plies++;
-        }
-    }
+    int w;
+    if (is_win<1>(g, s)) w = ((s.occP & g.corner_br) || s.occN == 0) ? nj : 0;
+    else w = run_playouts<1>(&T, pstate_from(g, s), g.S,
+                             PlayoutRng::chunk_word(obs_id ? obs_id[m] : (u32)m, (u32)(i * total + r0), 0x4D435453u, key), nj);
     if (w) atomicAdd(&wins[(size_t)m * 6 + i], w);
 }
 
@@ -865,12 +871,14 @@ int ewn_predict_mcts(int board_size, int cube_layer, int M, const int8_t *boards
 static int mcts_launch(const Geom &g, int M, const int8_t *boards, const int8_t *dice, const uint8_t *active, int total, u64 key,
                        const u32 *obs_id, int8_t *actions, int32_t *wins, hipStream_t s)
 {
-    const long long threads = (long long)M * 6 * ((total + MCTS_RPT - 1) / MCTS_RPT);
+    const bool lean = g.CN <= 6;
+    const long long threads = (long long)M * 6 * (lean ? (total + PLAYOUT_CHAIN - 1) / PLAYOUT_CHAIN : total);
     if (threads > 0x7fffffffll * BS) return EWN_EINVAL;
     BY_NW(g, (k_mcts_init<1><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, active, wins)),
           (k_mcts_init<2><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, active, wins)));
-    BY_NW(g, (k_mcts_rollout<1><<<GRID(threads), BS, 0, s>>>(g, M, total, boards, dice, obs_id, key, wins)),
-          (k_mcts_rollout<2><<<GRID(threads), BS, 0, s>>>(g, M, total, boards, dice, obs_id, key, wins)));
+    if (lean) k_mcts_rollout_lean<<<GRID(threads), BS, 0, s>>>(g, M, total, boards, dice, obs_id, key, wins);
+    else BY_NW(g, (k_mcts_rollout<1><<<GRID(threads), BS, 0, s>>>(g, M, total, boards, dice, obs_id, key, wins)),
+               (k_mcts_rollout<2><<<GRID(threads), BS, 0, s>>>(g, M, total, boards, dice, obs_id, key, wins)));
     BY_NW(g, (k_mcts_pick<1><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, wins, actions)),
           (k_mcts_pick<2><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, wins, actions)));
     return launch_status();
@@ -1013,7 +1021,13 @@ int ewn_playout_wins(int board_size, int cube_layer, int M, const int8_t *boards
     if (!wins) return EWN_ENULL;
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(wins, 0, (size_t)M * sizeof(int32_t), s) != hipSuccess) return EWN_ELAUNCH;
+    if (g.CN <= 6) {
+        const long long threads = (long long)M * ((n_sims + PLAYOUT_CHAIN - 1) / PLAYOUT_CHAIN);
+        k_playout_wins_lean<<<GRID(threads), BS, 0, s>>>(g, M, n_sims, boards, first_player, key, wins);
+        return launch_status();
+    }
     const long long threads = (long long)M * n_sims;
+    if (threads > 0x7fffffffll * BS) return EWN_EINVAL;
     BY_NW(g, (k_playout_wins<1><<<GRID(threads), BS, 0, s>>>(g, M, n_sims, boards, first_player, key, wins)),
           (k_playout_wins<2><<<GRID(threads), BS, 0, s>>>(g, M, n_sims, boards, first_player, key, wins)));
     return launch_status();
