@@ -417,7 +417,7 @@ __global__ __launch_bounds__(BS) void k_playout_wins(Geom g, int M, int n_sims, 
     GState<NW> s;
     decode_board<NW>(g, boards + (size_t)m * g.cells, s);
     PlayoutRng ps;
-    ps.seed(PlayoutRng::chunk_word((u32)m, (u32)(r - r % PLAYOUT_CHAIN), 0x53494D55u, key), (u32)(r % PLAYOUT_CHAIN));
+    ps.seed(PlayoutRng::obs_word((u32)m, 0x53494D55u, key), (u32)r);
     int cur = first_player == 1 ? 0 : 1;
     for (int ply = 0; ply < 1024 && !is_win<NW>(g, s); ply++) {
         if (cur == 0) rollout_ply<0, NW>(g, s, ps); else rollout_ply<1, NW>(g, s, ps);
@@ -426,27 +426,32 @@ __global__ __launch_bounds__(BS) void k_playout_wins(Geom g, int M, int n_sims, 
     if ((s.occP & g.corner_br) || s.occN == 0) atomicAdd(&wins[m], 1);
 }
 
-// the same for cube_layer <= 3: one thread per (position, chunk of PLAYOUT_CHAIN playouts), ewn_playout.hpp
-__global__ __launch_bounds__(BS) void k_playout_wins_lean(Geom g, int M, int n_sims, const int8_t *boards, int first_player, u64 key,
-                                                          int32_t *wins)
+// the same for cube_layer <= 3 (ewn_playout.hpp): an aligned group of 2^gl lanes per position, lane t plays playouts
+// t, t + 2^gl, ... back to back
+__global__ __launch_bounds__(BS) void k_playout_wins_lean(Geom g, int M, int n_sims, int gl, const int8_t *boards, int first_player,
+                                                          u64 key, int32_t *wins)
 {
     __shared__ PlayTab T;
     playtab_build(&T, g.S);
     __syncthreads();
-    const int chunks = (n_sims + PLAYOUT_CHAIN - 1) / PLAYOUT_CHAIN;
     const long long idx = (long long)blockIdx.x * BS + threadIdx.x;
-    if (idx >= (long long)M * chunks) return;
-    const int m = (int)(idx / chunks), r0 = (int)(idx % chunks) * PLAYOUT_CHAIN, nj = min(PLAYOUT_CHAIN, n_sims - r0);
-    GState<1> s;
-    decode_board<1>(g, boards + (size_t)m * g.cells, s);
-    int w;
-    if (is_win<1>(g, s)) w = ((s.occP & g.corner_br) || s.occN == 0) ? nj : 0;
-    else {
-        const PState b0 = pstate_from(g, s);
-        const u32 word = PlayoutRng::chunk_word((u32)m, (u32)r0, 0x53494D55u, key);
-        w = first_player == 1 ? run_playouts<0>(&T, b0, g.S, word, nj) : run_playouts<1>(&T, b0, g.S, word, nj);
+    const int tc = 1 << gl, lane = (int)(idx & (tc - 1));
+    const long long m = idx >> gl;
+    int w = 0;
+    if (m < M && lane < n_sims) {
+        const int nj = (n_sims - lane + tc - 1) >> gl;
+        GState<1> s;
+        decode_board<1>(g, boards + (size_t)m * g.cells, s);
+        if (is_win<1>(g, s)) w = ((s.occP & g.corner_br) || s.occN == 0) ? nj : 0;
+        else {
+            const PState b0 = pstate_from(g, s);
+            const u32 word = PlayoutRng::obs_word((u32)m, 0x53494D55u, key);
+            w = first_player == 1 ? run_playouts<0>(&T, b0, g.S, word, (u32)lane, (u32)tc, nj)
+                                  : run_playouts<1>(&T, b0, g.S, word, (u32)lane, (u32)tc, nj);
+        }
     }
-    if (w) atomicAdd(&wins[m], w);
+    for (int off = tc >> 1; off > 0; off >>= 1) w += __shfl_down(w, off, tc); // groups never straddle a wave
+    if (lane == 0 && m < M && w) atomicAdd(&wins[m], w);
 }
 
 template <int NW>
@@ -587,8 +592,7 @@ __global__ __launch_bounds__(BS) void k_mcts_rollout(Geom g, int M, int total, c
         apply_move<0, NW>(g, s, mk, md);
     }
     PlayoutRng ps;
-    ps.seed(PlayoutRng::chunk_word(obs_id ? obs_id[m] : (u32)m, (u32)(i * total + r - r % PLAYOUT_CHAIN), 0x4D435453u, key),
-            (u32)(r % PLAYOUT_CHAIN));
+    ps.seed(PlayoutRng::obs_word(obs_id ? obs_id[m] : (u32)m, 0x4D435453u, key), (u32)(i * total + r));
     int cur = 1; // BOTTOM_RIGHT replies first, mcts.py:26
     for (int ply = 0; ply < 1024 && !is_win<NW>(g, s); ply++) {
         if (cur == 0) rollout_ply<0, NW>(g, s, ps); else rollout_ply<1, NW>(g, s, ps);
@@ -597,33 +601,45 @@ __global__ __launch_bounds__(BS) void k_mcts_rollout(Geom g, int M, int total, c
     if ((s.occP & g.corner_br) || s.occN == 0) atomicAdd(&wins[(size_t)m * 6 + i], 1); // mcts.py:39-41
 }
 
-// the same for cube_layer <= 3: thread (observation m, root move i, chunk c) plays playouts c*PLAYOUT_CHAIN .. of that
-// root move back to back (ewn_playout.hpp).  Consecutive threads share (m, i): one base position per wave, broadcast loads.
-__global__ __launch_bounds__(BS) void k_mcts_rollout_lean(Geom g, int M, int total, const int8_t *boards, const int8_t *dice,
+// the same for cube_layer <= 3 (ewn_playout.hpp).  A block owns MCTS_OBS_PER_BLOCK observations = 60 root-move slots,
+// lists the slots that hold a move (k_mcts_init left wins >= 0 there), and its 256 >> gl aligned groups of 2^gl lanes
+// walk that list; lane t of a group plays playouts t, t + 2^gl, ... of the group's root move back to back.
+#define MCTS_OBS_PER_BLOCK 10
+__global__ __launch_bounds__(BS) void k_mcts_rollout_lean(Geom g, int M, int total, int gl, const int8_t *boards, const int8_t *dice,
                                                           const u32 *obs_id, u64 key, int32_t *wins)
 {
     __shared__ PlayTab T;
+    __shared__ uint8_t live[64];
+    __shared__ int nlive_s;
     playtab_build(&T, g.S);
-    __syncthreads();
-    const int chunks = (total + PLAYOUT_CHAIN - 1) / PLAYOUT_CHAIN;
-    const long long idx = (long long)blockIdx.x * BS + threadIdx.x;
-    const long long per = 6ll * chunks;
-    if (idx >= (long long)M * per) return;
-    const int m = (int)(idx / per), rem = (int)(idx % per), i = rem / chunks, r0 = (rem % chunks) * PLAYOUT_CHAIN;
-    if (wins[(size_t)m * 6 + i] < 0) return;
-    const int nj = min(PLAYOUT_CHAIN, total - r0);
-    GState<1> s;
-    decode_board<1>(g, boards + (size_t)m * g.cells, s);
-    {
-        int j = 0, mk = 0, md = 0;
-        for_each_legal<0, 1>(g, s, dice[m], [&](int, int k, int dir) { if (j == i) { mk = k; md = dir; } j++; return j <= i; });
-        apply_move<0, 1>(g, s, mk, md);
+    const long long cell0 = (long long)blockIdx.x * (MCTS_OBS_PER_BLOCK * 6);
+    if (threadIdx.x < 64) {
+        const long long cell = cell0 + threadIdx.x;
+        const bool lv = threadIdx.x < MCTS_OBS_PER_BLOCK * 6 && cell < (long long)M * 6 && wins[cell] >= 0;
+        const unsigned long long mask = __ballot(lv);
+        if (lv) live[__popcll(mask & ((1ull << threadIdx.x) - 1ull))] = (uint8_t)threadIdx.x;
+        if (threadIdx.x == 0) nlive_s = __popcll(mask);
     }
-    int w;
-    if (is_win<1>(g, s)) w = ((s.occP & g.corner_br) || s.occN == 0) ? nj : 0;
-    else w = run_playouts<1>(&T, pstate_from(g, s), g.S,
-                             PlayoutRng::chunk_word(obs_id ? obs_id[m] : (u32)m, (u32)(i * total + r0), 0x4D435453u, key), nj);
-    if (w) atomicAdd(&wins[(size_t)m * 6 + i], w);
+    __syncthreads();
+    const int nlive = nlive_s, tc = 1 << gl, lane = threadIdx.x & (tc - 1);
+    const int nj = lane < total ? (total - lane + tc - 1) >> gl : 0;
+    for (int slot = threadIdx.x >> gl; slot < nlive; slot += BS >> gl) {
+        const long long cell = cell0 + live[slot];
+        const int m = (int)(cell / 6), i = (int)(cell % 6);
+        int w = 0;
+        if (nj > 0) {
+            GState<1> s;
+            decode_board<1>(g, boards + (size_t)m * g.cells, s);
+            int j = 0, mk = 0, md = 0;
+            for_each_legal<0, 1>(g, s, dice[m], [&](int, int k, int dir) { if (j == i) { mk = k; md = dir; } j++; return j <= i; });
+            apply_move<0, 1>(g, s, mk, md);
+            if (is_win<1>(g, s)) w = ((s.occP & g.corner_br) || s.occN == 0) ? nj : 0;
+            else w = run_playouts<1>(&T, pstate_from(g, s), g.S, PlayoutRng::obs_word(obs_id ? obs_id[m] : (u32)m, 0x4D435453u, key),
+                                     (u32)(i * total + lane), (u32)tc, nj); // BOTTOM_RIGHT replies first, mcts.py:26
+        }
+        for (int off = tc >> 1; off > 0; off >>= 1) w += __shfl_down(w, off, tc); // groups never straddle a wave
+        if (lane == 0 && w) atomicAdd(&wins[cell], w);
+    }
 }
 
 template <int NW>
@@ -872,11 +888,10 @@ static int mcts_launch(const Geom &g, int M, const int8_t *boards, const int8_t 
                        const u32 *obs_id, int8_t *actions, int32_t *wins, hipStream_t s)
 {
     const bool lean = g.CN <= 6;
-    const long long threads = (long long)M * 6 * (lean ? (total + PLAYOUT_CHAIN - 1) / PLAYOUT_CHAIN : total);
-    if (threads > 0x7fffffffll * BS) return EWN_EINVAL;
+    const long long threads = lean ? (((long long)M + MCTS_OBS_PER_BLOCK - 1) / MCTS_OBS_PER_BLOCK) * BS : (long long)M * 6 * total;
     BY_NW(g, (k_mcts_init<1><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, active, wins)),
           (k_mcts_init<2><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, active, wins)));
-    if (lean) k_mcts_rollout_lean<<<GRID(threads), BS, 0, s>>>(g, M, total, boards, dice, obs_id, key, wins);
+    if (lean) k_mcts_rollout_lean<<<GRID(threads), BS, 0, s>>>(g, M, total, playout_group_log2(total), boards, dice, obs_id, key, wins);
     else BY_NW(g, (k_mcts_rollout<1><<<GRID(threads), BS, 0, s>>>(g, M, total, boards, dice, obs_id, key, wins)),
                (k_mcts_rollout<2><<<GRID(threads), BS, 0, s>>>(g, M, total, boards, dice, obs_id, key, wins)));
     BY_NW(g, (k_mcts_pick<1><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, wins, actions)),
@@ -1022,8 +1037,10 @@ int ewn_playout_wins(int board_size, int cube_layer, int M, const int8_t *boards
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(wins, 0, (size_t)M * sizeof(int32_t), s) != hipSuccess) return EWN_ELAUNCH;
     if (g.CN <= 6) {
-        const long long threads = (long long)M * ((n_sims + PLAYOUT_CHAIN - 1) / PLAYOUT_CHAIN);
-        k_playout_wins_lean<<<GRID(threads), BS, 0, s>>>(g, M, n_sims, boards, first_player, key, wins);
+        const int gl = playout_group_log2(n_sims);
+        const long long threads = (long long)M << gl;
+        if (threads > 0x7fffffffll * BS) return EWN_EINVAL;
+        k_playout_wins_lean<<<GRID(threads), BS, 0, s>>>(g, M, n_sims, gl, boards, first_player, key, wins);
         return launch_status();
     }
     const long long threads = (long long)M * n_sims;
