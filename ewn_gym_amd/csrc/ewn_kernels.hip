@@ -432,22 +432,24 @@ __global__ __launch_bounds__(BS) void k_playout_wins_lean(Geom g, int M, int n_s
                                                           u64 key, int32_t *wins)
 {
     __shared__ PlayTab T;
+    __shared__ int next[BS / 8];
     playtab_build(&T, g.S);
     __syncthreads();
     const long long idx = (long long)blockIdx.x * BS + threadIdx.x;
     const int tc = 1 << gl, lane = (int)(idx & (tc - 1));
     const long long m = idx >> gl;
+    int *nx = &next[threadIdx.x >> gl];
+    if (lane == 0) *nx = tc; // same wave as the lanes that read it: LDS operations of a wave execute in order
     int w = 0;
-    if (m < M && lane < n_sims) {
-        const int nj = (n_sims - lane + tc - 1) >> gl;
+    if (m < M) {
         GState<1> s;
         decode_board<1>(g, boards + (size_t)m * g.cells, s);
-        if (is_win<1>(g, s)) w = ((s.occP & g.corner_br) || s.occN == 0) ? nj : 0;
+        if (is_win<1>(g, s)) w = ((s.occP & g.corner_br) || s.occN == 0) ? (lane < n_sims ? (n_sims - lane + tc - 1) >> gl : 0) : 0;
         else {
             const PState b0 = pstate_from(g, s);
             const u32 word = PlayoutRng::obs_word((u32)m, 0x53494D55u, key);
-            w = first_player == 1 ? run_playouts<0>(&T, b0, g.S, word, (u32)lane, (u32)tc, nj)
-                                  : run_playouts<1>(&T, b0, g.S, word, (u32)lane, (u32)tc, nj);
+            w = first_player == 1 ? run_playouts<0>(&T, b0, g.S, word, 0u, lane, n_sims, nx)
+                                  : run_playouts<1>(&T, b0, g.S, word, 0u, lane, n_sims, nx);
         }
     }
     for (int off = tc >> 1; off > 0; off >>= 1) w += __shfl_down(w, off, tc); // groups never straddle a wave
@@ -611,6 +613,7 @@ __global__ __launch_bounds__(BS) void k_mcts_rollout_lean(Geom g, int M, int tot
     __shared__ PlayTab T;
     __shared__ uint8_t live[64];
     __shared__ int nlive_s;
+    __shared__ int next[BS / 8];
     playtab_build(&T, g.S);
     const long long cell0 = (long long)blockIdx.x * (MCTS_OBS_PER_BLOCK * 6);
     if (threadIdx.x < 64) {
@@ -622,21 +625,20 @@ __global__ __launch_bounds__(BS) void k_mcts_rollout_lean(Geom g, int M, int tot
     }
     __syncthreads();
     const int nlive = nlive_s, tc = 1 << gl, lane = threadIdx.x & (tc - 1);
-    const int nj = lane < total ? (total - lane + tc - 1) >> gl : 0;
+    int *nx = &next[threadIdx.x >> gl];
     for (int slot = threadIdx.x >> gl; slot < nlive; slot += BS >> gl) {
         const long long cell = cell0 + live[slot];
         const int m = (int)(cell / 6), i = (int)(cell % 6);
-        int w = 0;
-        if (nj > 0) {
-            GState<1> s;
-            decode_board<1>(g, boards + (size_t)m * g.cells, s);
-            int j = 0, mk = 0, md = 0;
-            for_each_legal<0, 1>(g, s, dice[m], [&](int, int k, int dir) { if (j == i) { mk = k; md = dir; } j++; return j <= i; });
-            apply_move<0, 1>(g, s, mk, md);
-            if (is_win<1>(g, s)) w = ((s.occP & g.corner_br) || s.occN == 0) ? nj : 0;
-            else w = run_playouts<1>(&T, pstate_from(g, s), g.S, PlayoutRng::obs_word(obs_id ? obs_id[m] : (u32)m, 0x4D435453u, key),
-                                     (u32)(i * total + lane), (u32)tc, nj); // BOTTOM_RIGHT replies first, mcts.py:26
-        }
+        if (lane == 0) *nx = tc; // same wave as the lanes that read it: LDS operations of a wave execute in order
+        int w;
+        GState<1> s;
+        decode_board<1>(g, boards + (size_t)m * g.cells, s);
+        int j = 0, mk = 0, md = 0;
+        for_each_legal<0, 1>(g, s, dice[m], [&](int, int k, int dir) { if (j == i) { mk = k; md = dir; } j++; return j <= i; });
+        apply_move<0, 1>(g, s, mk, md);
+        if (is_win<1>(g, s)) w = ((s.occP & g.corner_br) || s.occN == 0) ? (lane < total ? (total - lane + tc - 1) >> gl : 0) : 0;
+        else w = run_playouts<1>(&T, pstate_from(g, s), g.S, PlayoutRng::obs_word(obs_id ? obs_id[m] : (u32)m, 0x4D435453u, key),
+                                 (u32)(i * total), lane, total, nx); // BOTTOM_RIGHT replies first, mcts.py:26
         for (int off = tc >> 1; off > 0; off >>= 1) w += __shfl_down(w, off, tc); // groups never straddle a wave
         if (lane == 0 && w) atomicAdd(&wins[cell], w);
     }

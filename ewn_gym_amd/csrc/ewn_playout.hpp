@@ -144,28 +144,33 @@ EWN_DEV bool playout_ply(const PlayTab *T, PState &st, u32 &A, PlayoutRng &ps, u
     return q == goal || A == 0u;
 }
 
-// nj playouts (numbers x0, x0 + stride, ...) from b0 with FIRST to move; returns how many TOP_LEFT won (mcts.py:39-41)
+// The playouts x0 .. x0 + total - 1 of one start position b0, FIRST to move, shared by the 2^gl lanes of a group: lane t
+// starts with playout t and takes the next unplayed one from *next (an LDS counter of the group, preset to 2^gl) whenever
+// it finishes, so the lanes of a wave stay busy until the position runs out of playouts.  Which lane plays which playout
+// does not matter: playout x always starts from seed(word, x).  Returns how many of this lane's playouts TOP_LEFT won
+// (mcts.py:39-41).
 template <int FIRST>
-EWN_DEV int run_playouts(const PlayTab *T, const PState &b0, int S, u32 word, u32 x0, u32 stride, int nj)
+EWN_DEV int run_playouts(const PlayTab *T, const PState &b0, int S, u32 word, u32 x0, int lane, int total, int *next)
 {
     const u32 goal0 = 9u * (u32)(S - 1);
     const u32 A0 = FIRST == 0 ? alive_bits(b0.plo, b0.phi) : alive_bits(b0.nlo, b0.nhi);
     PState st = b0;
-    u32 A = A0, x = x0;
+    u32 A = A0;
     PlayoutRng ps;
-    ps.seed(word, x);
-    int j = 0, w = 0;
+    ps.seed(word, x0 + (u32)lane);
+    bool busy = lane < total;
+    int w = 0;
     // a cube only ever moves towards its goal corner: a playout is at most 12 * 2 * (S - 1) plies; the cap is a guard only
-    for (int it = 0; it < nj * 256 && j < nj; it++) {
+    for (int it = 0; it < total * 256 && busy; it++) {
         bool fin = playout_ply<FIRST>(T, st, A, ps, FIRST == 0 ? goal0 : 0u);
         bool second_won = false;
         if (!fin) fin = second_won = playout_ply<1 - FIRST>(T, st, A, ps, FIRST == 0 ? 0u : goal0);
         if (fin) {
             w += ((FIRST == 0) != second_won) ? 1 : 0; // the side that made the last move won
-            j++;
-            x += stride;
+            const int r = atomicAdd(next, 1);
+            busy = r < total;
             st = b0; A = A0;
-            ps.seed(word, x);
+            ps.seed(word, x0 + (u32)r);
         }
     }
     return w;
