@@ -433,6 +433,7 @@ __global__ __launch_bounds__(BS) void k_playout_wins_lean(Geom g, int M, int n_s
 {
     __shared__ PlayTab T;
     __shared__ int next[BS / 8];
+    __shared__ u32 gw[BS / 8][4];
     playtab_build(&T, g.S);
     __syncthreads();
     const long long idx = (long long)blockIdx.x * BS + threadIdx.x;
@@ -442,11 +443,10 @@ __global__ __launch_bounds__(BS) void k_playout_wins_lean(Geom g, int M, int n_s
     if (lane == 0) *nx = tc; // same wave as the lanes that read it: LDS operations of a wave execute in order
     int w = 0;
     if (m < M) {
-        GState<1> s;
-        decode_board<1>(g, boards + (size_t)m * g.cells, s);
-        if (is_win<1>(g, s)) w = ((s.occP & g.corner_br) || s.occN == 0) ? (lane < n_sims ? (n_sims - lane + tc - 1) >> gl : 0) : 0;
+        const PState b0 = pstate_load(g, boards + (size_t)m * g.cells, lane, tc, gw[threadIdx.x >> gl]);
+        bool tl;
+        if (pstate_is_win(b0, g.S, tl)) w = tl && lane < n_sims ? (n_sims - lane + tc - 1) >> gl : 0;
         else {
-            const PState b0 = pstate_from(g, s);
             const u32 word = PlayoutRng::obs_word((u32)m, 0x53494D55u, key);
             w = first_player == 1 ? run_playouts<0>(&T, b0, g.S, word, 0u, lane, n_sims, nx)
                                   : run_playouts<1>(&T, b0, g.S, word, 0u, lane, n_sims, nx);
@@ -614,6 +614,7 @@ __global__ __launch_bounds__(BS) void k_mcts_rollout_lean(Geom g, int M, int tot
     __shared__ uint8_t live[64];
     __shared__ int nlive_s;
     __shared__ int next[BS / 8];
+    __shared__ u32 gw[BS / 8][4];
     playtab_build(&T, g.S);
     const long long cell0 = (long long)blockIdx.x * (MCTS_OBS_PER_BLOCK * 6);
     if (threadIdx.x < 64) {
@@ -631,13 +632,9 @@ __global__ __launch_bounds__(BS) void k_mcts_rollout_lean(Geom g, int M, int tot
         const int m = (int)(cell / 6), i = (int)(cell % 6);
         if (lane == 0) *nx = tc; // same wave as the lanes that read it: LDS operations of a wave execute in order
         int w;
-        GState<1> s;
-        decode_board<1>(g, boards + (size_t)m * g.cells, s);
-        int j = 0, mk = 0, md = 0;
-        for_each_legal<0, 1>(g, s, dice[m], [&](int, int k, int dir) { if (j == i) { mk = k; md = dir; } j++; return j <= i; });
-        apply_move<0, 1>(g, s, mk, md);
-        if (is_win<1>(g, s)) w = ((s.occP & g.corner_br) || s.occN == 0) ? (lane < total ? (total - lane + tc - 1) >> gl : 0) : 0;
-        else w = run_playouts<1>(&T, pstate_from(g, s), g.S, PlayoutRng::obs_word(obs_id ? obs_id[m] : (u32)m, 0x4D435453u, key),
+        PState b0 = pstate_load(g, boards + (size_t)m * g.cells, lane, tc, gw[threadIdx.x >> gl]);
+        if (playout_root_move(&T, b0, g.S, dice[m], i)) w = lane < total ? (total - lane + tc - 1) >> gl : 0; // TOP_LEFT has won
+        else w = run_playouts<1>(&T, b0, g.S, PlayoutRng::obs_word(obs_id ? obs_id[m] : (u32)m, 0x4D435453u, key),
                                  (u32)(i * total), lane, total, nx); // BOTTOM_RIGHT replies first, mcts.py:26
         for (int off = tc >> 1; off > 0; off >>= 1) w += __shfl_down(w, off, tc); // groups never straddle a wave
         if (lane == 0 && w) atomicAdd(&wins[cell], w);

@@ -96,38 +96,57 @@ EWN_DEV u32 alive_bits(u32 lo, u32 hi)
     return (__umul24(z, 0x1041u) >> 12) & 0x3Fu;       // bit pairs 0-1, 8-9, 16-17 land on 12-13, 14-15, 16-17
 }
 
-EWN_DEV PState pstate_from(const Geom &g, const GState<1> &s)
+// The 2^gl lanes of a group (one wave at most) read one board together: lane t looks at cells t, t + 2^gl, ... and xors
+// the cubes it finds into the group's four LDS words gw[0..3]; every lane returns the finished position.  LDS operations of
+// one wave execute in program order, so no barrier is needed.  (A cube number that appears twice garbles that byte; the
+// tables are sized so that any byte value is a safe index.)
+EWN_DEV PState pstate_load(const Geom &g, const int8_t *board, int lane, int tc, u32 *gw)
 {
-    u32 w[4] = { 0x40404040u, 0x40404040u, 0x40404040u, 0x40404040u };
+    if (lane < 4) gw[lane] = 0x40404040u;
+    __builtin_amdgcn_wave_barrier();
     const u32 magic = 65536u / (u32)g.S + 1u; // (c * magic) >> 16 == c / S for c < 64, S in 3..8
-    #pragma unroll
-    for (int k = 0; k < 6; k++) {
-        #pragma unroll
-        for (int side = 0; side < 2; side++) {
-            const u32 alive = side == 0 ? s.aliveP : s.aliveN;
-            const u32 c = (u32)(side == 0 ? pos_of<0>(s, k) : pos_of<1>(s, k));
-            const u32 row = (c * magic) >> 16, cell8 = row * 8u + (c - row * (u32)g.S);
-            const int sh = 8 * (k >> 1);
-            if ((alive >> k) & 1u) w[side * 2 + (k & 1)] = (w[side * 2 + (k & 1)] & ~(0xFFu << sh)) | (cell8 << sh);
+    for (int c = lane; c < g.cells; c += tc) {
+        const int v = board[c], k = (v > 0 ? v : -v) - 1;
+        if (v != 0 && k < 6) {
+            const u32 row = ((u32)c * magic) >> 16, cell8 = row * 8u + ((u32)c - row * (u32)g.S);
+            atomicXor(&gw[(v < 0 ? 2 : 0) + (k & 1)], (0x40u ^ cell8) << (8 * (k >> 1)));
         }
     }
-    return PState{ w[0], w[1], w[2], w[3] };
+    __builtin_amdgcn_wave_barrier();
+    const PState st = { gw[0], gw[1], gw[2], gw[3] };
+    __builtin_amdgcn_wave_barrier();
+    return st;
+}
+
+// some byte of w equals cell q (q < 64)
+EWN_DEV bool pstate_on(u32 w, u32 q)
+{
+    const u32 q7 = q ^ 0x7Fu, qb = __builtin_amdgcn_perm(q7, q7, 0u);
+    return (((w ^ qb) + 0x01010101u) & 0x80808080u) != 0u;
+}
+
+// check_win, envs/ewn.py:131-142; top_left_won as mcts.py:39-41 reads it
+EWN_DEV bool pstate_is_win(const PState &st, int S, bool &top_left_won)
+{
+    const u32 goal = 9u * (u32)(S - 1);
+    const bool p_home = pstate_on(st.plo, goal) || pstate_on(st.phi, goal), n_home = pstate_on(st.nlo, 0u) || pstate_on(st.nhi, 0u);
+    const bool p_none = alive_bits(st.plo, st.phi) == 0u, n_none = alive_bits(st.nlo, st.nhi) == 0u;
+    top_left_won = p_home || n_none;
+    return p_home || n_home || p_none || n_none;
 }
 
 // One uniformly random legal move of SIDE (mcts.py:29-35).  A: in = SIDE's cubes on the board, out = the other side's
 // after the move.  Returns true when the move ends the game, which the mover then has won: a move can reach only the
 // mover's own goal corner and can empty only the other side (the mover itself stays), envs/ewn.py:131-142.
-template <int SIDE>
-EWN_DEV bool playout_ply(const PlayTab *T, PState &st, u32 &A, PlayoutRng &ps, u32 goal)
+template <int SIDE, class Pick>
+EWN_DEV bool playout_move(const PlayTab *T, PState &st, u32 &A, u32 d, Pick &&pick_of, u32 goal)
 {
     u32 &mlo = SIDE == 0 ? st.plo : st.nlo, &mhi = SIDE == 0 ? st.phi : st.nhi;
-    u32 d, frac;
-    ps.draw(d, frac);
     const u32 sel = T->sel[A * 8u + d];
     const u32 pp = __builtin_amdgcn_perm(mhi, mlo, sel | 0x0C0C0000u); // cells of the first and the second candidate cube
     const u32 p0 = pp & 0xFFu, p1 = pp >> 8;                             // no second cube: p1 = 0x40, legal[..][0x40] = 0
     const u32 okm = (u32)T->legal[SIDE][p0] | ((u32)T->legal[SIDE][p1] << 3);
-    const u32 r = T->nth[okm * 8u + PlayoutRng::pick(frac, (u32)__popc(okm))];
+    const u32 r = T->nth[okm * 8u + pick_of((u32)__popc(okm))];
     const bool second = r > 127u;
     const u32 p = second ? p1 : p0, byte = second ? sel >> 8 : sel & 0xFFu, delta = r & 0x7Fu;
     const u32 q = SIDE == 0 ? p + delta : p - delta;
@@ -142,6 +161,21 @@ EWN_DEV bool playout_ply(const PlayTab *T, PState &st, u32 &A, PlayoutRng &ps, u
     mhi ^= (u32)(mv >> 32);
     A = SIDE == 0 ? alive_bits(st.nlo, st.nhi) : alive_bits(st.plo, st.phi);
     return q == goal || A == 0u;
+}
+
+template <int SIDE>
+EWN_DEV bool playout_ply(const PlayTab *T, PState &st, u32 &A, PlayoutRng &ps, u32 goal)
+{
+    u32 d, frac;
+    ps.draw(d, frac);
+    return playout_move<SIDE>(T, st, A, d, [&](u32 n) { return PlayoutRng::pick(frac, n); }, goal);
+}
+
+// TOP_LEFT's idx-th legal action for this dice (get_legal_actions order, envs/ewn.py:338-375): the root move of mcts.py:21-24
+EWN_DEV bool playout_root_move(const PlayTab *T, PState &st, int S, int dice, int idx)
+{
+    u32 A = alive_bits(st.plo, st.phi);
+    return playout_move<0>(T, st, A, (u32)(dice - 1), [&](u32) { return (u32)idx; }, 9u * (u32)(S - 1));
 }
 
 // The playouts x0 .. x0 + total - 1 of one start position b0, FIRST to move, shared by the 2^gl lanes of a group: lane t
@@ -176,10 +210,13 @@ EWN_DEV int run_playouts(const PlayTab *T, const PState &b0, int S, u32 word, u3
     return w;
 }
 
-// lanes per group of playouts sharing one start position: 8..64, about six playouts or more per lane
+// lanes per group of playouts sharing one start position: 8..64, about PLAYOUT_PER_LANE playouts or more per lane
+#ifndef PLAYOUT_PER_LANE
+#define PLAYOUT_PER_LANE 6
+#endif
 static inline int playout_group_log2(int total)
 {
     int l = 3;
-    while (l < 6 && (total >> (l + 1)) >= 6) l++;
+    while (l < 6 && (total >> (l + 1)) >= PLAYOUT_PER_LANE) l++;
     return l;
 }
