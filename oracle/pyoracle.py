@@ -114,6 +114,16 @@ def predict_mcts(boards, dice, num_simulations=10, num_env_copies=5, key=0, obs_
     return acts, wins
 
 
+def playout_wins(boards, first_player, n_sims=100, key=0, cube_layer=3):
+    boards = _i8(boards)
+    M, S = boards.shape[0], boards.shape[1]
+    wins = np.zeros(M, np.int32)
+    rc = lib().ewn_oracle_playout_wins(C.c_int(S), C.c_int(cube_layer), C.c_int(M), _p(boards), C.c_int(first_player), C.c_int(n_sims),
+                                       C.c_uint64(key), _p(wins))
+    assert rc == 0
+    return wins
+
+
 def philox(ctr, key):
     c = np.asarray(ctr, np.uint32)
     k = np.asarray(key, np.uint32)

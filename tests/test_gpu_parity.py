@@ -397,6 +397,34 @@ def test_predict_mcts_bit_exact_vs_oracle(ea):
     assert np.array_equal(cpu(wins), ow) and np.array_equal(cpu(acts), oa)
 
 
+@pytest.mark.parametrize("S,L,n,total", [(5, 3, 24, 7), (6, 3, 40, 20), (6, 3, 33, 100), (8, 3, 21, 130), (5, 3, 50, 400), (5, 3, 7, 1),
+                                         (7, 4, 24, 9), (7, 5, 16, 5), (8, 5, 12, 11)])
+def test_predict_mcts_every_geometry_and_group_size(ea, S, L, n, total):
+    """cube_layer <= 3 runs the byte-per-cube playout (ewn_playout.hpp) with 8..64 lanes per root move, larger layers the
+    generic one; both must reproduce the oracle's win counts exactly, late-game positions (few cubes) included."""
+    b, d = _random_positions(S, L, n, 100 + S + L, max_steps=30)
+    d = np.minimum(d, L * (L + 1) // 2).astype(np.int8)
+    acts, wins = ea.predict_mcts(b, d, num_simulations=total, num_env_copies=1, key=S * 1000 + total, cube_layer=L)
+    oa, ow = po.predict_mcts(b, d, num_simulations=total, num_env_copies=1, key=S * 1000 + total, cube_layer=L)
+    assert np.array_equal(cpu(wins), ow) and np.array_equal(cpu(acts), oa)
+
+
+@pytest.mark.parametrize("S,L,n_sims,first", [(5, 3, 100, 2), (5, 3, 37, 1), (7, 3, 64, 2), (8, 3, 9, 1), (7, 4, 20, 2)])
+def test_playout_wins_bit_exact_vs_oracle(ea, S, L, n_sims, first):
+    """MinimaxEnv.simulate (envs/minimax_ewn.py:215-238) on reachable positions AND on finished games (no playout is played)."""
+    b, _ = _random_positions(S, L, 48, 500 + S, max_steps=30)
+    done = b[:6].copy()
+    done[0][done[0] == 1] = 0
+    done[0, S - 1, S - 1] = 1      # TOP_LEFT already home
+    done[1][done[1] == -1] = 0
+    done[1, 0, 0] = -1             # BOTTOM_RIGHT already home
+    done[2][done[2] < 0] = 0       # no negative cube left
+    done[3][done[3] > 0] = 0       # no positive cube left
+    b = np.concatenate([b, done[:4]])
+    wins = ea.playout_wins(b, first_player=first, n_sims=n_sims, key=77 + S, cube_layer=L)
+    assert np.array_equal(cpu(wins), po.playout_wins(b, first, n_sims, key=77 + S, cube_layer=L))
+
+
 def test_g9_mcts_statistics_vs_reference(ea, golden):
     g = golden("g9_mcts.json")
     for (S, L) in sorted({(r["S"], r["L"]) for r in g}):
