@@ -603,11 +603,18 @@ __global__ __launch_bounds__(BS) void k_mcts_rollout(Geom g, int M, int total, c
     if ((s.occP & g.corner_br) || s.occN == 0) atomicAdd(&wins[(size_t)m * 6 + i], 1); // mcts.py:39-41
 }
 
-// the same for cube_layer <= 3 (ewn_playout.hpp).  A block owns MCTS_OBS_PER_BLOCK observations = 60 root-move slots,
-// lists the slots that hold a move (k_mcts_init left wins >= 0 there), and its 256 >> gl aligned groups of 2^gl lanes
-// walk that list; lane t of a group plays playouts t, t + 2^gl, ... of the group's root move back to back.
-#define MCTS_OBS_PER_BLOCK 10
-__global__ __launch_bounds__(BS) void k_mcts_rollout_lean(Geom g, int M, int total, int gl, const int8_t *boards, const int8_t *dice,
+// the same for cube_layer <= 3 (ewn_playout.hpp).  A block owns opb <= 10 observations = up to 60 root-move slots, lists
+// the slots that hold a move (k_mcts_init left wins >= 0 there), and its 256 >> gl aligned groups of 2^gl lanes walk that
+// list; the lanes of a group share the playouts of the group's root move (run_playouts).
+// Measured (MI355X, ms per step): 7x7/400 playouts (4 groups): opb 10 -> 1.76, 5 -> 1.63, 3 -> 1.58, 2 -> 1.60;
+// 5x5/50 playouts (32 groups): opb 10 -> 0.417, 5 -> 0.446, 3 -> 0.535: about 0.8 live slots per group and pass.
+static inline int mcts_obs_per_block(int gl)
+{
+    const int groups = BS >> gl, opb = (3 * groups + 2) / 4;
+    return opb < 2 ? 2 : (opb > 10 ? 10 : opb);
+}
+
+__global__ __launch_bounds__(BS) void k_mcts_rollout_lean(Geom g, int M, int total, int gl, int opb, const int8_t *boards, const int8_t *dice,
                                                           const u32 *obs_id, u64 key, int32_t *wins)
 {
     __shared__ PlayTab T;
@@ -616,10 +623,10 @@ __global__ __launch_bounds__(BS) void k_mcts_rollout_lean(Geom g, int M, int tot
     __shared__ int next[BS / 8];
     __shared__ u32 gw[BS / 8][4];
     playtab_build(&T, g.S);
-    const long long cell0 = (long long)blockIdx.x * (MCTS_OBS_PER_BLOCK * 6);
+    const long long cell0 = (long long)blockIdx.x * (opb * 6);
     if (threadIdx.x < 64) {
         const long long cell = cell0 + threadIdx.x;
-        const bool lv = threadIdx.x < MCTS_OBS_PER_BLOCK * 6 && cell < (long long)M * 6 && wins[cell] >= 0;
+        const bool lv = (int)threadIdx.x < opb * 6 && cell < (long long)M * 6 && wins[cell] >= 0;
         const unsigned long long mask = __ballot(lv);
         if (lv) live[__popcll(mask & ((1ull << threadIdx.x) - 1ull))] = (uint8_t)threadIdx.x;
         if (threadIdx.x == 0) nlive_s = __popcll(mask);
@@ -887,10 +894,12 @@ static int mcts_launch(const Geom &g, int M, const int8_t *boards, const int8_t 
                        const u32 *obs_id, int8_t *actions, int32_t *wins, hipStream_t s)
 {
     const bool lean = g.CN <= 6;
-    const long long threads = lean ? (((long long)M + MCTS_OBS_PER_BLOCK - 1) / MCTS_OBS_PER_BLOCK) * BS : (long long)M * 6 * total;
+    const int gl = playout_group_log2(total), opb = mcts_obs_per_block(gl);
+    const long long threads = lean ? (((long long)M + opb - 1) / opb) * BS : (long long)M * 6 * total;
+    if (threads > 0x7fffffffll * BS) return EWN_EINVAL;
     BY_NW(g, (k_mcts_init<1><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, active, wins)),
           (k_mcts_init<2><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, active, wins)));
-    if (lean) k_mcts_rollout_lean<<<GRID(threads), BS, 0, s>>>(g, M, total, playout_group_log2(total), boards, dice, obs_id, key, wins);
+    if (lean) k_mcts_rollout_lean<<<GRID(threads), BS, 0, s>>>(g, M, total, gl, opb, boards, dice, obs_id, key, wins);
     else BY_NW(g, (k_mcts_rollout<1><<<GRID(threads), BS, 0, s>>>(g, M, total, boards, dice, obs_id, key, wins)),
                (k_mcts_rollout<2><<<GRID(threads), BS, 0, s>>>(g, M, total, boards, dice, obs_id, key, wins)));
     BY_NW(g, (k_mcts_pick<1><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, wins, actions)),
