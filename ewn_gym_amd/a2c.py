@@ -22,15 +22,49 @@ import torch
 import torch.nn as nn
 
 
+class _SplitKLinearFn(torch.autograd.Function):
+    """y = x W^T + b whose weight gradient dW = dy^T x is computed as P partial products over slices of the batch.
+
+    The training batch is n_steps * lanes = 3 x 10^5 rows against 64-wide layers: dy^T x is a [64 x B] x [B x 64] product,
+    all reduction and a single output tile, which the library GEMM runs on a handful of CUs (rocprofv3: 0.43-0.54 ms each,
+    six per update = half of the update).  As a batched product over P slices it fills the chip (one bmm + one sum)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return torch.addmm(bias, x, weight.t())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        B = x.shape[0]
+        P = 1
+        while P < 512 and B % (2 * P) == 0 and B // (2 * P) >= 256:
+            P *= 2
+        dx = dy @ weight if ctx.needs_input_grad[0] else None
+        if P > 1:
+            dw = torch.bmm(dy.reshape(P, B // P, -1).transpose(1, 2), x.reshape(P, B // P, -1)).sum(0)
+        else:
+            dw = dy.t() @ x
+        return dx, dw, dy.sum(0)
+
+
+class SplitKLinear(nn.Linear):
+    def forward(self, x):
+        if x.dim() == 2 and x.shape[0] >= 4096 and torch.is_grad_enabled():
+            return _SplitKLinearFn.apply(x.contiguous(), self.weight, self.bias)
+        return super().forward(x)
+
+
 class ActorCritic(nn.Module):
     def __init__(self, board_size=5, cube_num=6, hidden=64):
         super().__init__()
         self.S, self.cube_num = board_size, cube_num
         feat = board_size * board_size + cube_num + 1
-        self.pi = nn.Sequential(nn.Linear(feat, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh())
-        self.vf = nn.Sequential(nn.Linear(feat, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh())
-        self.action_net = nn.Linear(hidden, 5)   # logits of MultiDiscrete([2, 3])
-        self.value_net = nn.Linear(hidden, 1)
+        self.pi = nn.Sequential(SplitKLinear(feat, hidden), nn.Tanh(), SplitKLinear(hidden, hidden), nn.Tanh())
+        self.vf = nn.Sequential(SplitKLinear(feat, hidden), nn.Tanh(), SplitKLinear(hidden, hidden), nn.Tanh())
+        self.action_net = SplitKLinear(hidden, 5)   # logits of MultiDiscrete([2, 3])
+        self.value_net = SplitKLinear(hidden, 1)
         for seq in (self.pi, self.vf):
             for m in seq:
                 if isinstance(m, nn.Linear):

@@ -82,3 +82,23 @@ def test_single_bucket_gradient_all_reduce_with_two_gloo_ranks():
         assert p.exitcode == 0
     mean = (res[0][0] + res[1][0]) / 2
     assert torch.allclose(res[0][1], mean, atol=1e-7) and torch.allclose(res[1][1], mean, atol=1e-7)
+
+
+def test_split_k_linear_matches_nn_linear():
+    """The batched-partial-product weight gradient (a2c.SplitKLinear) is the same gradient as nn.Linear's, up to fp32 summation order."""
+    from ewn_gym_amd.a2c import SplitKLinear
+    torch.manual_seed(0)
+    a = SplitKLinear(32, 64)
+    b = torch.nn.Linear(32, 64)
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(8192, 32, requires_grad=True)
+    x2 = x.detach().clone().requires_grad_(True)
+    ya, yb = a(x), b(x2)
+    g = torch.randn_like(ya)
+    ya.backward(g)
+    yb.backward(g)
+    assert torch.equal(ya, yb) and torch.equal(x.grad, x2.grad)
+    assert torch.allclose(a.weight.grad, b.weight.grad, rtol=1e-4, atol=1e-3)
+    assert torch.allclose(a.bias.grad, b.bias.grad, rtol=1e-4, atol=1e-3)
+    small = torch.randn(16, 32)
+    assert torch.equal(a(small), b(small))
