@@ -41,12 +41,20 @@ struct FastTab {
     uint16_t lutx[72];                           // clz(P mask) -> t*8*IXN   (entry for an empty mask: 0)
     uint16_t luty[72];                           // clz(N mask) -> t*8
     uint8_t ri[64];                              // canonical row-major cell -> ring index
-    uint8_t nbp[3][64];                          // mover   (TOP_LEFT):     ring index -> destination ring index, 255 = off board
-    uint8_t nbn[3][64];                          // replier (BOTTOM_RIGHT): ring index -> destination ring index, 255 = off board
+    // position bytes (ewn_step_d3.hpp: one byte per cube = its ring index, bit 6 set once it is off the board) index the
+    // next five tables directly, so they have 128 entries: 64..127 = "no such cube" -> off board / no legal direction
+    uint8_t nbp[3][128];                         // mover   (TOP_LEFT):     ring index -> destination ring index, 255 = off board
+    uint8_t nbn[3][128];                         // replier (BOTTOM_RIGHT): ring index -> destination ring index, 255 = off board
+    uint8_t lgp[128], lgn[128];                  // ring index -> legal directions of a TOP_LEFT / BOTTOM_RIGHT cube there (bits 0..2)
     int32_t nv, ri_origin, pad0, pad1;           // number of ranks; ring index of cell (0,0)
     // for the fused step kernel (ewn_step_d3.hpp), which keeps the game in canonical ring space:
     uint8_t real_of_ring[64];                    // ring index -> REAL row-major cell (canonical cell = S*S-1 - real cell)
     uint64_t init_P, init_N, init_posP, init_posN; // the start position (envs/ewn.py:94-107): opponent = P side, agent = N side
+    // find_near_cube / get_legal_actions (envs/ewn.py:144-176, 338-375) as a table: [cubes on board (bit k = cube k+1) * 8 +
+    // dice - 1] -> first | second << 8 | first_is_larger_neighbour << 15, where first / second are the (0-based) cubes whose
+    // moves make up the legal list in the reference's order; 6 = none (byte 6 of a position word is permanently off board)
+    uint16_t sel[512];
+    uint8_t nth[512];                            // [6-bit legal mask * 8 + k] -> index of its k-th set bit (0 when there is none)
 };
 
 // LDS / device image size: the struct padded to 4 KiB so the LDS-DMA copy needs no tail handling
@@ -83,7 +91,7 @@ static int build_fast_tables(FastTab<S> *T)
     for (int c = 0; c < 64; c++) T->ri[c] = c < S * S ? (uint8_t)ring_of_rm[c] : 0;
     T->ri_origin = ring_of_rm[0];
     for (int d = 0; d < 3; d++)
-        for (int q = 0; q < 64; q++) {
+        for (int q = 0; q < 128; q++) {
             T->nbp[d][q] = 255; T->nbn[d][q] = 255;
             if (q >= S * S) continue;
             const int c = rm_of_ring[q], i = c / S, j = c % S;
@@ -91,15 +99,40 @@ static int build_fast_tables(FastTab<S> *T)
             if (i + di < S && j + dj < S) T->nbp[d][q] = (uint8_t)ring_of_rm[(i + di) * S + (j + dj)];
             if (i - di >= 0 && j - dj >= 0) T->nbn[d][q] = (uint8_t)ring_of_rm[(i - di) * S + (j - dj)];
         }
+    for (int q = 0; q < 128; q++) {
+        T->lgp[q] = T->lgn[q] = 0;
+        for (int d = 0; d < 3; d++) {
+            if (T->nbp[d][q] != 255) T->lgp[q] |= (uint8_t)(1u << d);
+            if (T->nbn[d][q] != 255) T->lgn[q] |= (uint8_t)(1u << d);
+        }
+    }
+    for (int e = 0; e < 512; e++) {
+        const unsigned alive = (unsigned)e >> 3;
+        const int d = e & 7; // dice - 1; 6 and 7 cannot be rolled but keep find_near_cube's answer for them
+        int up = -1, down = -1;
+        for (int k = d + 1; k < 6; k++) if ((alive >> k) & 1u) { up = k; break; }
+        for (int k = (d < 6 ? d : 6) - 1; k >= 0; k--) if ((alive >> k) & 1u) { down = k; break; }
+        int first = 6, second = 6, larger = 0;
+        if (d < 6 && ((alive >> d) & 1u)) first = d;
+        else if (up >= 0) { first = up; larger = 1; if (down >= 0) second = down; }
+        else if (down >= 0) first = down;
+        T->sel[e] = (uint16_t)(first | (second << 8) | (larger << 15));
+        unsigned m = (unsigned)e >> 3;
+        for (int i = 0; i < (e & 7); i++) m &= m - 1;
+        int j = 0;
+        while (m && !((m >> j) & 1u)) j++;
+        T->nth[e] = (uint8_t)(m ? j : 0);
+    }
     for (int q = 0; q < 64; q++) T->real_of_ring[q] = q < S * S ? (uint8_t)(S * S - 1 - rm_of_ring[q]) : 0;
+    T->init_posP = T->init_posN = 0x4040ull << 48; // bytes 6 and 7: no such cube
     {
         int cnt = 1;
         for (int i = 1; i <= 3; i++)
             for (int j = 0; j < i; j++) {
                 const int cpos = j * S + (i - j - 1), cneg = (S - 1 - j) * S + (S - i + j); // real cells of +cnt / -cnt
                 const int rN = ring_of_rm[S * S - 1 - cpos], rP = ring_of_rm[S * S - 1 - cneg];
-                T->init_N |= 1ull << rN; T->init_posN |= (uint64_t)rN << (6 * (cnt - 1));
-                T->init_P |= 1ull << rP; T->init_posP |= (uint64_t)rP << (6 * (cnt - 1));
+                T->init_N |= 1ull << rN; T->init_posN |= (uint64_t)rN << (8 * (cnt - 1));
+                T->init_P |= 1ull << rP; T->init_posP |= (uint64_t)rP << (8 * (cnt - 1));
                 cnt++;
             }
     }

@@ -946,8 +946,8 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
                          fused_refill ? scratch : nullptr };
             const int gpb = gpb0;
             const dim3 grid((unsigned)(step_blocks + refill_blocks));
-            // LDS: boards + terminal boards | tables | (MT) this block's parked refill requests; a refill block needs (W+1) x 65 words
-            size_t l3 = (((size_t)2 * gpb * g.cells + 15) & ~(size_t)15);
+            // LDS: boards + terminal boards | tables | decode scatter area | (MT) this block's parked refill requests; a refill block needs (W+1) x 65 words
+            size_t l3 = (((size_t)2 * gpb * g.cells + 15) & ~(size_t)15) + (size_t)gpb * 16; // + d3_decode's 16 bytes per game
             if (fused_refill) l3 += 16 + (size_t)2 * gpb * 16;
             const size_t need_refill = fused_refill ? (size_t)(k.W + 1) * 65 * 4 : 0;
 #define D3_LDS(SS) (l3 + FAST_TAB_BYTES(SS) > need_refill ? l3 + FAST_TAB_BYTES(SS) : need_refill)

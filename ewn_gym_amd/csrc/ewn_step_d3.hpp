@@ -50,45 +50,57 @@ template <int T, int J> struct Bcast {
 #define DPP_XOR1 0xB1 /* quad_perm [1,0,3,2] */
 #define DPP_XOR2 0x4E /* quad_perm [2,3,0,1] */
 
-// Packed 6-bit fields
-EWN_DEV int pk_get(u64 w, int k) { return (int)((w >> (6 * k)) & 63ull); }
-EWN_DEV u64 pk_set(u64 w, int k, int c) { return (w & ~(63ull << (6 * k))) | ((u64)c << (6 * k)); }
+// A side's six cubes: byte k of a u64 = ring index of cube k (0-based), bit 6 set once the cube is off the board (the low six
+// bits are then stale); bytes 6 and 7 are permanently "off the board", which is what a table answers "no such cube" with.
+EWN_DEV int pk_get(u64 w, int k) { return (int)((w >> (8 * k)) & 0xFFull); }
+#define PK_OFF 0x40   // flag in a position byte
+#define PK_PADS (0x4040ull << 48)
 
 template <int S>
 struct RState {                 // one game, canonical ring space
     typename MaskOf<S>::type P, N; // P: canonical TOP_LEFT (the opponent), N: canonical BOTTOM_RIGHT (the agent)
-    u64 posP, posN;             // ring index of cube k at bits [6k, 6k+6)
-    u32 aliveP, aliveN;
+    u64 posP, posN;
 };
 
-template <int S>
-EWN_DEV void rs_kill(RState<S> &s, int side_is_P, int q)
+// bit k = cube k is on the board
+EWN_DEV u32 pk_alive(u64 w)
 {
-    typedef typename MaskOf<S>::type M;
-    const M one = 1;
-    u32 a = side_is_P ? s.aliveP : s.aliveN;
-    const u64 pos = side_is_P ? s.posP : s.posN;
-    #pragma unroll
-    for (int k = 0; k < 6; k++)
-        if (((a >> k) & 1u) && pk_get(pos, k) == q) a &= ~(1u << k);
-    if (side_is_P) { s.aliveP = a; s.P &= ~(one << q); } else { s.aliveN = a; s.N &= ~(one << q); }
+    const u32 t = (~(u32)w & 0x40404040u) >> 6, u = ~(u32)(w >> 32);   // t: bits 0, 8, 16, 24
+    return ((t | (t >> 7) | (t >> 14) | (t >> 21)) & 0xFu) | ((u >> 2) & 0x10u) | ((u >> 9) & 0x20u);
+}
+
+// FastTab::sel entry for the side whose cubes are pos: which cube(s) may move for this dice
+template <int S>
+EWN_DEV u32 pk_sel(const FastTab<S> *Tb, u64 pos, int dice) { return Tb->sel[pk_alive(pos) * 8u + ((u32)(dice - 1) & 7u)]; }
+// ring bytes of the first (bits 0-7) and second (bits 8-15) cube of a sel entry; "none" reads a permanently-off byte
+EWN_DEV u32 pk_pair(u64 pos, u32 e) { return __builtin_amdgcn_perm((u32)(pos >> 32), (u32)pos, (e & 0x0707u) | 0x0C0C0000u); }
+// find_cube_to_move (envs/ewn.py:178-215): the dice cube if it is on the board (then it is the only entry); else the
+// requested neighbour if it exists, else the other one; 6 when the side has no cube at all
+EWN_DEV int pk_cube(u32 e, bool larger) { const int first = (int)(e & 7u), second = (int)((e >> 8) & 7u); return (larger || second == 6) ? first : second; }
+
+// whatever stands on ring cell q leaves the board (envs/ewn.py:254-258): byte == q  <=>  bit 7 of ((byte ^ q ^ 0x7F) + 1);
+// bytes never reach 0x80, so the additions do not carry between bytes
+EWN_DEV u64 pk_capture(u64 w, u32 qb)
+{
+    u32 lo = (u32)w, hi = (u32)(w >> 32);
+    lo |= (((lo ^ qb) + 0x01010101u) >> 1) & 0x40404040u;
+    hi |= (((hi ^ qb) + 0x01010101u) >> 1) & 0x40404040u;
+    return ((u64)hi << 32) | lo;
 }
 
 // move cube k of one side to ring cell q (capture whatever is there, own cube included: envs/ewn.py:252-261)
-template <int S>
-EWN_DEV void rs_move(RState<S> &s, bool mover_is_P, int k, int q)
+template <int S, bool MOVER_IS_P>
+EWN_DEV void rs_move(RState<S> &s, int k, int q)
 {
     typedef typename MaskOf<S>::type M;
     const M one = 1, bq = one << q;
-    if (mover_is_P) {
-        if (s.N & bq) rs_kill<S>(s, 0, q); else if (s.P & bq) rs_kill<S>(s, 1, q);
-        s.P = (s.P & ~(one << pk_get(s.posP, k))) | bq;
-        s.posP = pk_set(s.posP, k, q);
-    } else {
-        if (s.P & bq) rs_kill<S>(s, 1, q); else if (s.N & bq) rs_kill<S>(s, 0, q);
-        s.N = (s.N & ~(one << pk_get(s.posN, k))) | bq;
-        s.posN = pk_set(s.posN, k, q);
-    }
+    const int p = pk_get(MOVER_IS_P ? s.posP : s.posN, k) & 63;
+    const u32 q7 = (u32)q ^ 0x7Fu, qb = __builtin_amdgcn_perm(q7, q7, 0u);
+    s.posP = pk_capture(s.posP, qb);
+    s.posN = pk_capture(s.posN, qb);
+    const u64 mv = (u64)(u32)(p ^ q) << (8 * k);
+    if (MOVER_IS_P) { s.posP ^= mv; s.P = (s.P & ~(one << p)) | bq; s.N &= ~bq; }
+    else { s.posN ^= mv; s.N = (s.N & ~(one << p)) | bq; s.P &= ~bq; }
 }
 
 // Depth-3 hybrid search in ring space, shared by T lanes (sub = my index in the group).
@@ -107,14 +119,14 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
     u32 legal = 0, hits_origin = 0, mine_alive = 0;
     #pragma unroll
     for (int i = 0; i < KPT; i++) {
-        const int k = sub + T * i;          // may be >= 6 for the last slot when 6 % T != 0: treated as a dead cube
-        const bool real = k < 6;
-        rnk[i] = pk_get(c.posN, real ? k : 0);
+        const int k = sub + T * i;          // may be >= 6 for the last slot when 6 % T != 0: byte 6/7 = a cube that is off the board
+        const int rb = pk_get(c.posN, k < 6 ? k : 6);
+        rnk[i] = rb & 63;
         rclr[i] = ~(one << rnk[i]);
-        mine_alive |= ((real && ((c.aliveN >> k) & 1u)) ? 1u : 0u) << i;
+        mine_alive |= ((rb & PK_OFF) ? 0u : 1u) << i;
         #pragma unroll
         for (int d = 0; d < 3; d++) {
-            const int dn = Tb->nbn[d][rnk[i]];
+            const int dn = Tb->nbn[d][rb];
             const bool ok = dn != 255;
             rset[i][d] = ok ? (one << dn) : (M)0;
             legal |= (ok ? 1u : 0u) << (i * 3 + d);
@@ -123,10 +135,11 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
     }
 
     // root slots: <= 2 cubes x 3 dirs in the reference's list order (envs/ewn.py:338-375)
-    const CubeSel cs = select_cubes(c.aliveP, dice);
-    const bool have0 = cs.exact || cs.has_up, have1 = !cs.exact && cs.has_down;
-    const int flag0 = cs.exact ? 0 : 1;
-    const int rp0 = pk_get(c.posP, have0 ? (cs.exact ? cs.k_exact : cs.k_up) : 0), rp1 = pk_get(c.posP, have1 ? cs.k_down : 0);
+    const u32 rsel = pk_sel<S>(Tb, c.posP, dice), rpp = pk_pair(c.posP, rsel);
+    const int rb0 = (int)(rpp & 0xFFu), rb1 = (int)(rpp >> 8);
+    const bool have0 = !(rb0 & PK_OFF), have1 = !(rb1 & PK_OFF);
+    const int flag0 = (int)(rsel >> 15);
+    const int rp0 = rb0 & 63, rp1 = rb1 & 63;
 
     double best = -__builtin_inf(); // alpha = max(alpha, best_val): the running best (root beta stays +inf)
     bflag = 0; bdir = 0;
@@ -230,12 +243,15 @@ __device__ __forceinline__ double fast_d3(const FastTab<S> *Tb, const GState<1> 
 {
     typedef typename MaskOf<S>::type M;
     RState<S> s;
-    s.P = 0; s.N = 0; s.posP = 0; s.posN = 0; s.aliveP = c.aliveP & 63u; s.aliveN = c.aliveN & 63u;
+    s.P = 0; s.N = 0; s.posP = s.posN = PK_PADS;
     #pragma unroll
     for (int k = 0; k < 6; k++) {
         const int rp = Tb->ri[pos_get<1>(c.posP, k)], rn = Tb->ri[pos_get<1>(c.posN, k)];
-        if ((c.aliveP >> k) & 1u) { s.P |= (M)1 << rp; s.posP |= (u64)rp << (6 * k); }
-        if ((c.aliveN >> k) & 1u) { s.N |= (M)1 << rn; s.posN |= (u64)rn << (6 * k); }
+        const bool ap = (c.aliveP >> k) & 1u, an = (c.aliveN >> k) & 1u;
+        if (ap) s.P |= (M)1 << rp;
+        if (an) s.N |= (M)1 << rn;
+        s.posP |= (u64)(ap ? rp : PK_OFF) << (8 * k);
+        s.posN |= (u64)(an ? rn : PK_OFF) << (8 * k);
     }
     return d3_search<S, 1>(Tb, s, dice, 0, bflag, bdir);
 }
@@ -259,15 +275,18 @@ struct D3Buf {
 
 // real board bytes -> canonical ring state.  Real value v > 0 is the agent's cube v (canonical BOTTOM_RIGHT side),
 // v < 0 the opponent's cube |v| (canonical TOP_LEFT side); real cell c sits at canonical cell S*S-1-c, whose ring
-// index is a compile-time constant.  The T lanes of a game scan interleaved cells and OR their partial states.
+// index is a compile-time constant.  The T lanes of a game scan interleaved cells: a cell's ring index is scattered
+// into byte (v + 8) of the game's 16 LDS bytes ga (7..2 = opponent cubes 1..6, 8 = empty cells, 9..14 = agent cubes 1..6),
+// which every lane then reads back whole; the occupancy masks are OR-ed across the lanes with DPP.  LDS operations of
+// one wave execute in program order, so the T lanes (same wave) need no barrier.
 template <int S, int T>
-EWN_DEV void d3_decode(const int8_t *b, int sub, RState<S> &s)
+EWN_DEV void d3_decode(const int8_t *b, int sub, uint8_t *ga, RState<S> &s)
 {
     typedef typename MaskOf<S>::type M;
     constexpr RingGeo<S> G{};
+    *(uint4 *)ga = make_uint4(0x40404040u, 0x40404040u, 0x40404040u, 0x40404040u); // every cube off the board
+    __builtin_amdgcn_wave_barrier();
     M P = 0, N = 0;
-    u64 posP = 0, posN = 0;
-    u32 aP = 0, aN = 0;
     #pragma unroll
     for (int c0 = 0; c0 < S * S; c0 += T) {
         #pragma unroll
@@ -277,29 +296,26 @@ EWN_DEV void d3_decode(const int8_t *b, int sub, RState<S> &s)
             const bool mine = T == 1 || sub == j;
             const int v = mine ? (int)b[c] : 0;
             const int ring = G.ring_of_rm[S * S - 1 - c];
-            const u32 mpos = (u32)((0 - v) >> 31), mneg = (u32)(v >> 31);   // all ones where v > 0 / v < 0
-            const int k1 = max(v, 0 - v);                                       // |v|, 0 for an empty cell
-            const u32 abit = (1u << ((k1 - 1) & 31)) & 63u;                     // empty cell: bit 31 -> masked off
-            const u64 pbits = (u64)ring << ((6 * k1 - 6) & 63);
-            N |= (M)((M)1 << ring) & (M)(M)(0 - (M)(mpos & 1u));
-            P |= (M)((M)1 << ring) & (M)(M)(0 - (M)(mneg & 1u));
-            aN |= abit & mpos; aP |= abit & mneg;
-            posN |= pbits & (0ull - (u64)(mpos & 1u)); posP |= pbits & (0ull - (u64)(mneg & 1u));
+            ga[(v + 8) & 15] = (uint8_t)ring;                                   // lanes that do not own the cell hit the "empty" byte
+            const M mpos = (M)(long long)((0 - v) >> 31), mneg = (M)(long long)(v >> 31); // all ones where v > 0 / v < 0
+            N |= ((M)1 << ring) & mpos;
+            P |= ((M)1 << ring) & mneg;
         }
     }
+    __builtin_amdgcn_wave_barrier();
+    const uint4 x = *(const uint4 *)ga;
+    __builtin_amdgcn_wave_barrier();
+    s.posN = ((((u64)x.w << 32) | x.z) >> 8) | (0x40ull << 56);                              // bytes 9..14 -> 0..5
+    s.posP = ((u64)__builtin_bswap32(x.x) << 32) | __builtin_bswap32(x.y);                   // bytes 7..2 -> 0..5, 1..0 -> 6..7
     if constexpr (T >= 2) {
-        #define D3_OR32(x, ctrl) x |= dpp_u32<ctrl>(x)
         #define D3_OR64(x, ctrl) x |= ((u64)dpp_u32<ctrl>((u32)(x >> 32)) << 32) | dpp_u32<ctrl>((u32)x)
-        u64 P64 = (u64)P, N64 = (u64)N;
-        D3_OR64(P64, DPP_XOR1); D3_OR64(N64, DPP_XOR1); D3_OR64(posP, DPP_XOR1); D3_OR64(posN, DPP_XOR1); D3_OR32(aP, DPP_XOR1); D3_OR32(aN, DPP_XOR1);
-        if constexpr (T == 4) {
-            D3_OR64(P64, DPP_XOR2); D3_OR64(N64, DPP_XOR2); D3_OR64(posP, DPP_XOR2); D3_OR64(posN, DPP_XOR2); D3_OR32(aP, DPP_XOR2); D3_OR32(aN, DPP_XOR2);
-        }
-        P = (M)P64; N = (M)N64;
-        #undef D3_OR32
+        #define D3_ORM(x, ctrl) do { if constexpr (sizeof(M) == 4) x |= (M)dpp_u32<ctrl>((u32)x); else { u64 t_ = (u64)x; D3_OR64(t_, ctrl); x = (M)t_; } } while (0)
+        D3_ORM(P, DPP_XOR1); D3_ORM(N, DPP_XOR1);
+        if constexpr (T == 4) { D3_ORM(P, DPP_XOR2); D3_ORM(N, DPP_XOR2); }
+        #undef D3_ORM
         #undef D3_OR64
     }
-    s.P = P; s.N = N; s.posP = posP; s.posN = posN; s.aliveP = aP; s.aliveN = aN;
+    s.P = P; s.N = N;
 }
 
 // canonical ring state -> real board bytes (LDS), the T lanes writing interleaved shares
@@ -308,11 +324,18 @@ EWN_DEV void d3_encode(const FastTab<S> *Tb, const RState<S> &s, int sub, int8_t
 {
     #pragma unroll
     for (int c = 0; c < S * S; c++) if (T == 1 || c % T == sub) b[c] = 0;
+    // the table reads first (all in flight together), then the stores
+    int cell[12];
+    #pragma unroll
+    for (int k = 0; k < 6; k++) {
+        cell[2 * k] = Tb->real_of_ring[pk_get(s.posN, k) & 63];
+        cell[2 * k + 1] = Tb->real_of_ring[pk_get(s.posP, k) & 63];
+    }
     __builtin_amdgcn_wave_barrier(); // the zeroing of every lane of the group is issued before any cube byte
     #pragma unroll
     for (int k = 0; k < 6; k++) {
-        if (T == 1 || (2 * k) % T == sub) if ((s.aliveN >> k) & 1u) b[Tb->real_of_ring[pk_get(s.posN, k)]] = (int8_t)(k + 1);
-        if (T == 1 || (2 * k + 1) % T == sub) if ((s.aliveP >> k) & 1u) b[Tb->real_of_ring[pk_get(s.posP, k)]] = (int8_t)(-(k + 1));
+        if (T == 1 || (2 * k) % T == sub) if (!(pk_get(s.posN, k) & PK_OFF)) b[cell[2 * k]] = (int8_t)(k + 1);
+        if (T == 1 || (2 * k + 1) % T == sub) if (!(pk_get(s.posP, k) & PK_OFF)) b[cell[2 * k + 1]] = (int8_t)(-(k + 1));
     }
 }
 
@@ -320,7 +343,7 @@ template <int S>
 EWN_DEV void d3_init_state(const FastTab<S> *Tb, RState<S> &s)
 {
     typedef typename MaskOf<S>::type M;
-    s.P = (M)Tb->init_P; s.N = (M)Tb->init_N; s.posP = Tb->init_posP; s.posN = Tb->init_posN; s.aliveP = s.aliveN = 63u;
+    s.P = (M)Tb->init_P; s.N = (M)Tb->init_N; s.posP = Tb->init_posP; s.posN = Tb->init_posN;
 }
 
 // EinsteinWuerfeltNichtEnv.step (envs/ewn.py:436-486), minimax(depth 3, hybrid) opponent, cube_layer 3.
@@ -372,7 +395,8 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
     int8_t *tb = lds + ((2 * GPB * CELLS + 15) & ~15);
     tables_to_lds<FAST_TAB_BYTES(S)>(tb, (const int8_t *)B.tables); // LDS-DMA, waited for at the barrier
     const FastTab<S> *Tb = (const FastTab<S> *)tb;
-    [[maybe_unused]] u32 *qlds = (u32 *)(tb + FAST_TAB_BYTES(S)); // [0] = requests parked by this block, then up to 2*GPB x uint4
+    uint8_t *garr = (uint8_t *)(tb + FAST_TAB_BYTES(S));          // 16 bytes per game: d3_decode's scatter area
+    [[maybe_unused]] u32 *qlds = (u32 *)(garr + GPB * 16);        // [0] = requests parked by this block, then up to 2*GPB x uint4
     if constexpr (RNGK == 0) { if (B.mtq && threadIdx.x == 0) qlds[0] = 0; }
 
     const int g0 = ((int)blockIdx.x - c.refill_blocks) * GPB, ng = min(GPB, c.N - g0);
@@ -402,18 +426,17 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
     [[maybe_unused]] u32 epoch = 0;
     if constexpr (RNGK == 0) { if (live) { r.prefetch_next(B.rng, c.N, game); epoch = *rng_epoch_ptr(B.rng, c.N, c.W, game); } }
     r.begin_step();
-    d3_decode<S, T>(live ? mine : lds, sub, s); // every lane takes part (DPP combine); non-live lanes read game 0 of the block
+    d3_decode<S, T>(live ? mine : lds, sub, garr + gl * 16, s); // every lane takes part (DPP combine); non-live lanes read game 0 of the block
     const bool active = live && !frozen;
     bool reply = false;
     if (frozen) term = 1; // no reference counterpart: a finished, un-reset game stays put
     if (active) {
         // agent half, envs/ewn.py:438-458 (the agent is the canonical BOTTOM_RIGHT side)
-        const CubeSel cs = select_cubes(s.aliveN, dice);
-        const int k = cube_to_move(cs, aflag == 1);
-        const int q = (k >= 0 && adir >= 0 && adir <= 2) ? Tb->nbn[adir][pk_get(s.posN, k)] : 255;
+        const int k = pk_cube(pk_sel<S>(Tb, s.posN, dice), aflag == 1);
+        const int q = (adir >= 0 && adir <= 2) ? Tb->nbn[adir][pk_get(s.posN, k)] : 255; // no cube at all: byte 6 -> 255
         if (q == 255) { reward = -c.reward; term = 1; trunc = 1; info = EWN_INFO_INVALID_PLAYER; }
         else {
-            rs_move<S>(s, false, k, q);
+            rs_move<S, false>(s, k, q);
             if (q == Tb->ri_origin || s.P == 0) { reward = c.reward; term = 1; info = EWN_INFO_WON; }
             else { dice = r.randint(1, 7); reply = true; }
         }
@@ -424,28 +447,19 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
     if constexpr (OPP == 0) d3_search<S, T>(Tb, s, dice, sub, oflag, odir);
     if (reply) {
         // opponent half, envs/ewn.py:464-486
-        const CubeSel cs = select_cubes(s.aliveP, dice);
+        const u32 e = pk_sel<S>(Tb, s.posP, dice);
         if constexpr (OPP == 1) {
             // uniform index into the opponent's legal list (reference order: larger-neighbour cube first, dirs ascending),
             // drawn from the lane's own dice stream like the reference's shared global stream
-            const bool have0 = cs.exact || cs.has_up, have1 = !cs.exact && cs.has_down;
-            const int p0 = pk_get(s.posP, have0 ? (cs.exact ? cs.k_exact : cs.k_up) : 0), p1 = pk_get(s.posP, have1 ? cs.k_down : 0);
-            u32 okm = 0;
-            #pragma unroll
-            for (int d = 0; d < 3; d++) {
-                okm |= ((have0 && Tb->nbp[d][p0] != 255) ? 1u : 0u) << d;
-                okm |= ((have1 && Tb->nbp[d][p1] != 255) ? 1u : 0u) << (3 + d);
-            }
-            const int pick = r.randint(0, __popc(okm));
-            u32 m = okm;
-            for (int i = 0; i < pick; i++) m &= m - 1;   // drop the `pick` lowest set bits
-            const int slot = __ffs((int)m) - 1;           // 0..5 = cube slot * 3 + dir
-            oflag = slot < 3 ? (cs.exact ? 0 : 1) : 0;
+            const u32 pp = pk_pair(s.posP, e);
+            const u32 okm = (u32)Tb->lgp[pp & 0xFFu] | ((u32)Tb->lgp[pp >> 8] << 3);
+            const int slot = Tb->nth[okm * 8u + (u32)r.randint(0, __popc(okm))]; // 0..5 = cube slot * 3 + dir
+            oflag = slot < 3 ? (int)(e >> 15) : 0;
             odir = slot < 3 ? slot : slot - 3;
         }
-        const int k = cube_to_move(cs, oflag == 1);
+        const int k = pk_cube(e, oflag == 1);
         const int q = Tb->nbp[odir][pk_get(s.posP, k)];
-        rs_move<S>(s, true, k, q);
+        rs_move<S, true>(s, k, q);
         if (q == CELLS - 1 || s.N == 0) { reward = -c.reward; term = 1; info = EWN_INFO_LOST; }
         else dice = r.randint(1, 7);
     }
@@ -477,20 +491,13 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
         // RandomAgent.predict on the post-step observation (the agent is the canonical BOTTOM_RIGHT side)
         int f = 0, d = 0;
         if (!(frozen || (term && !c.autoreset))) {
-            const CubeSel cs = select_cubes(s.aliveN, dice);
-            const bool have0 = cs.exact || cs.has_up, have1 = !cs.exact && cs.has_down;
-            const int p0 = pk_get(s.posN, have0 ? (cs.exact ? cs.k_exact : cs.k_up) : 0), p1 = pk_get(s.posN, have1 ? cs.k_down : 0);
-            u32 okm = 0;
-            #pragma unroll
-            for (int dd = 0; dd < 3; dd++) {
-                okm |= ((have0 && Tb->nbn[dd][p0] != 255) ? 1u : 0u) << dd;
-                okm |= ((have1 && Tb->nbn[dd][p1] != 255) ? 1u : 0u) << (3 + dd);
-            }
+            const u32 e = pk_sel<S>(Tb, s.posN, dice), pp = pk_pair(s.posN, e);
+            const u32 okm = (u32)Tb->lgn[pp & 0xFFu] | ((u32)Tb->lgn[pp >> 8] << 3);
             const int n = __popc(okm);
             if (n > 0) {
                 const u32 w = agent_hash(r.seed, r.draws(), (u32)(c.lane_offset + game), c.key);
-                const int slot = nth_set_bit(okm, (int)__umulhi(w, (u32)n));
-                f = slot < 3 ? (cs.exact ? 0 : 1) : 0;
+                const int slot = Tb->nth[okm * 8u + __umulhi(w, (u32)n)];
+                f = slot < 3 ? (int)(e >> 15) : 0;
                 d = slot < 3 ? slot : slot - 3;
             }
         }
