@@ -492,3 +492,26 @@ def test_full_size_properties_and_sharding(ea):
         for k in range(6):
             x, o = cpu(full[t][k][lo:hi]), ores[k]
             assert np.array_equal(bits(x) if k == 2 else x, bits(o) if k == 2 else o), (t, k)
+
+
+def test_one_lane_per_game_variant_at_131072_lanes(ea):
+    """>= 131 072 lanes select the T = 1 instance of the lean step kernel (one lane per game); a slice against the oracle,
+    7x7 included (64-bit occupancy masks)."""
+    for S, N, T in ((5, 131072, 10), (7, 131072, 6)):
+        kw = dict(board_size=S, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=77, autoreset=True, seed_stride=N)
+        seeds = (np.arange(N, dtype=np.uint64) * 3 + 5).astype(np.uint32)
+        env = ea.VecEWN(N, **kw)
+        env.reset(seeds=seeds)
+        lo, hi = 70001, 70001 + 384
+        orc = po.OracleVecEnv(hi - lo, board_size=S, opponent="minimax", max_depth=3, rng="philox", philox_key=77, autoreset=True,
+                              seed_stride=N, lane_offset=lo)
+        orc.reset(seeds=seeds[lo:hi])
+        for t in range(T):
+            a = env.sample_legal_actions(t).clone()
+            oa = orc.sample_legal_actions(t)
+            assert np.array_equal(cpu(a[lo:hi]), oa)
+            res = env.step(a)
+            ores = orc.step(oa)
+            for k in range(6):
+                x, o = cpu(res[k][lo:hi]), ores[k]
+                assert np.array_equal(bits(x) if k == 2 else x, bits(o) if k == 2 else o), (S, t, k)
