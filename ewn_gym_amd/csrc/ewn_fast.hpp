@@ -173,5 +173,6 @@ static int build_fast_tables(FastTab<S> *T)
             const bool used = (ix % 8) >= 1 && (ix % 8) <= 6 && (iy % 8) >= 1 && (iy % 8) <= 6;
             T->rank[ix * IXN + iy] = used ? (uint16_t)(1 + (std::lower_bound(all.begin(), all.end(), e[(size_t)ix * IXN + iy]) - all.begin())) : 1;
         }
+    T->rank[0] = 1023; T->rank[1] = 1; // unused (level 0, count 0) slots that d3_search's leaf index is steered to
     return 0;
 }

@@ -754,11 +754,12 @@ static int d3_threads_per_game(int n_games)
 {
     static const int forced = [] { const char *e = getenv("EWN_D3_T"); return e ? atoi(e) : -1; }();
     if (forced == 0 || forced == 1 || forced == 2 || forced == 4) return forced;
-    // measured on MI355X at 65 536 games (rocprofv3 kernel time): T=1 30.3 us, T=2 25.3 us, T=4 31.6 us.  The kernel is
-    // bound by integer VALU issue (one wave-instruction per 4 cycles per SIMD), so lanes added beyond what hides the
-    // LDS/global latency only add redundant instructions.
-    if (n_games >= 131072) return 1;
-    if (n_games >= 8192) return 2;
+    // measured on MI355X (tools/sweep_T.sh, us per step, T = 1 / 2 / 4): 16 384 games 18.1 / 12.2 / 10.8; 32 768: 18.4 / 12.6 / 13.3;
+    // 65 536: 18.9 / 16.1 / 19.6; 131 072: 25.1 / 24.1 / 32.6; 262 144: 42.0 / 42.6 / 57.9; 1 048 576: 139.8 / 143.7 / 202.9.
+    // The kernel is bound by integer VALU issue once the chip is full, so lanes added beyond what hides the LDS/global
+    // latency only add redundant instructions.
+    if (n_games >= 262144) return 1;
+    if (n_games >= 32768) return 2;
     return 4;
 }
 

@@ -157,37 +157,66 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
         const M N1 = c.N & ~bd;
         const bool term = dest == FastTab<S>::CELLS - 1 || N1 == 0; // win(B1): value 10
 
-        // my leaves -> per cube: full minimum p2 and `cut` = the value at which the reference's reply loop would stop
-        // inside this cube's replies (`worst <= alpha`, minimax.py:59-61; alpha = best so far), 0 if it would not.
-        // The running minimum along a cube's replies is non-increasing, so the first one <= alpha is the largest one <= alpha.
+        // Four stages, each issuing ALL its LDS reads before the next one consumes them (sched_barrier keeps the compiler from
+        // re-serialising them into one round trip per leaf, which is what the register-pressure-driven schedule does):
+        // level tables -> ranks -> values of the three prefix minima -> cut.
         u32 tr[6];
+        constexpr int CH = KPT > 3 ? 3 : KPT; // cubes staged together: 9 leaves in flight; more only costs registers (T = 1: 186 VGPRs)
         #pragma unroll
-        for (int i = 0; i < KPT; i++) {
-            const bool alive1 = ((mine_alive >> i) & 1u) && rnk[i] != dest;
-            const M Nk = N1 & rclr[i];
-            u32 a[3];
+        for (int i0 = 0; i0 < KPT; i0 += CH) {
+            u32 lx[CH][3], ly[CH][3], keep[CH][3], fixed[CH][3], a[CH][3];
             #pragma unroll
-            for (int d = 0; d < 3; d++) {
-                const M N2 = Nk | rset[i][d];
-                const M P2 = P1 & ~rset[i][d];
-                const int ix = Tb->lutx[clz_m(P2)] + popc_m(P2) * IXN;
-                const int iy = Tb->luty[clz_m(N2)] + popc_m(N2);
-                u32 rk = Tb->rank[ix + iy];
-                rk = (P2 == 0 || ((hits_origin >> (i * 3 + d)) & 1u)) ? 1u : rk;   // -10 (rank 1): envs/minimax_ewn.py:45-47
-                a[d] = (alive1 && ((legal >> (i * 3 + d)) & 1u)) ? rk : 1023u;
+            for (int ii = 0; ii < CH; ii++) {
+                const int i = i0 + ii;
+                const bool alive1 = ((mine_alive >> i) & 1u) && rnk[i] != dest;
+                const M Nk = N1 & rclr[i];
+                #pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    const M N2 = Nk | rset[i][d];
+                    const M P2 = P1 & ~rset[i][d];
+                    lx[ii][d] = Tb->lutx[clz_m(P2)] + popc_m(P2) * IXN;
+                    ly[ii][d] = Tb->luty[clz_m(N2)] + popc_m(N2);
+                    // rank[0] = 1023 ("no such reply"), rank[1] = 1 (-10: envs/minimax_ewn.py:45-47).  The exceptions steer the
+                    // INDEX with and/or instead of selecting the loaded value: a select on a loaded value makes the compiler
+                    // branch around the LDS reads
+                    const bool absent = !(alive1 && ((legal >> (i * 3 + d)) & 1u));
+                    const bool lost = P2 == 0 || ((hits_origin >> (i * 3 + d)) & 1u);
+                    keep[ii][d] = (absent || lost) ? 0u : ~0u; fixed[ii][d] = absent ? 0u : (lost ? 1u : 0u);
+                }
             }
-            const u32 p1 = min(a[0], a[1]), p2 = min(p1, a[2]);
-            u32 cut = Tb->val[a[0]] <= best ? a[0] : 0u;       // val[1023] = +inf: an absent reply never cuts
-            cut = max(cut, Tb->val[p1] <= best ? p1 : 0u);
-            cut = max(cut, Tb->val[p2] <= best ? p2 : 0u);
-            const u32 mine = p2 | (cut << 10);                 // a cube that is off the board: p2 = 1023, cut = 0 -> FAST_NONE
-            // publish to the group: after this every lane holds tr[k] for all six cubes (cube k = j + T*i lives in lane j)
-            if constexpr (T == 1) tr[i] = mine;
-            else if constexpr (T == 2) { tr[2 * i] = dpp_u32<Bcast<2, 0>::CTRL>(mine); tr[2 * i + 1] = dpp_u32<Bcast<2, 1>::CTRL>(mine); }
-            else {
-                if (i == 0) { tr[0] = dpp_u32<Bcast<4, 0>::CTRL>(mine); tr[1] = dpp_u32<Bcast<4, 1>::CTRL>(mine);
-                              tr[2] = dpp_u32<Bcast<4, 2>::CTRL>(mine); tr[3] = dpp_u32<Bcast<4, 3>::CTRL>(mine); }
-                else { tr[4] = dpp_u32<Bcast<4, 0>::CTRL>(mine); tr[5] = dpp_u32<Bcast<4, 1>::CTRL>(mine); }
+            __builtin_amdgcn_sched_barrier(0);
+            #pragma unroll
+            for (int ii = 0; ii < CH; ii++) {
+                #pragma unroll
+                for (int d = 0; d < 3; d++) a[ii][d] = Tb->rank[((lx[ii][d] + ly[ii][d]) & keep[ii][d]) | fixed[ii][d]];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            u32 p1[CH], p2[CH];
+            double va[CH], v1[CH], v2[CH];
+            #pragma unroll
+            for (int ii = 0; ii < CH; ii++) {
+                p1[ii] = min(a[ii][0], a[ii][1]); p2[ii] = min(p1[ii], a[ii][2]);
+                va[ii] = Tb->val[a[ii][0]]; v1[ii] = Tb->val[p1[ii]]; v2[ii] = Tb->val[p2[ii]]; // val[1023] = +inf: an absent reply never cuts
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            #pragma unroll
+            for (int ii = 0; ii < CH; ii++) {
+                const int i = i0 + ii;
+                // per cube: full minimum p2 and `cut` = the value at which the reference's reply loop would stop inside this
+                // cube's replies (`worst <= alpha`, minimax.py:59-61; alpha = best so far), 0 if it would not.  The running
+                // minimum along a cube's replies is non-increasing, so the first one <= alpha is the largest one <= alpha.
+                u32 cut = va[ii] <= best ? a[ii][0] : 0u;
+                cut = max(cut, v1[ii] <= best ? p1[ii] : 0u);
+                cut = max(cut, v2[ii] <= best ? p2[ii] : 0u);
+                const u32 mine = p2[ii] | (cut << 10);             // a cube that is off the board: p2 = 1023, cut = 0 -> FAST_NONE
+                // publish to the group: after this every lane holds tr[k] for all six cubes (cube k = j + T*i lives in lane j)
+                if constexpr (T == 1) tr[i] = mine;
+                else if constexpr (T == 2) { tr[2 * i] = dpp_u32<Bcast<2, 0>::CTRL>(mine); tr[2 * i + 1] = dpp_u32<Bcast<2, 1>::CTRL>(mine); }
+                else {
+                    if (i == 0) { tr[0] = dpp_u32<Bcast<4, 0>::CTRL>(mine); tr[1] = dpp_u32<Bcast<4, 1>::CTRL>(mine);
+                                  tr[2] = dpp_u32<Bcast<4, 2>::CTRL>(mine); tr[3] = dpp_u32<Bcast<4, 3>::CTRL>(mine); }
+                    else { tr[4] = dpp_u32<Bcast<4, 0>::CTRL>(mine); tr[5] = dpp_u32<Bcast<4, 1>::CTRL>(mine); }
+                }
             }
         }
         // which cubes a dice value selects (find_near_cube): carry the nearest on-board cube's data along
@@ -284,23 +313,23 @@ EWN_DEV void d3_decode(const int8_t *b, int sub, uint8_t *ga, RState<S> &s)
 {
     typedef typename MaskOf<S>::type M;
     constexpr RingGeo<S> G{};
+    constexpr int NC = (S * S + T - 1) / T;
+    int v[NC]; // my cells first, all reads in flight together: the compiler cannot move a read of b across a write to ga
+    #pragma unroll
+    for (int i = 0; i < NC; i++) { const int c = i * T + sub; const bool in = c < S * S; v[i] = in ? (int)b[in ? c : 0] : 0; }
     *(uint4 *)ga = make_uint4(0x40404040u, 0x40404040u, 0x40404040u, 0x40404040u); // every cube off the board
     __builtin_amdgcn_wave_barrier();
     M P = 0, N = 0;
     #pragma unroll
-    for (int c0 = 0; c0 < S * S; c0 += T) {
+    for (int i = 0; i < NC; i++) {
+        // ring index of my i-th cell: a compile-time constant per (i, sub); select among the T candidates
+        int ring = 0;
         #pragma unroll
-        for (int j = 0; j < T; j++) {
-            const int c = c0 + j;
-            if (c >= S * S) continue;
-            const bool mine = T == 1 || sub == j;
-            const int v = mine ? (int)b[c] : 0;
-            const int ring = G.ring_of_rm[S * S - 1 - c];
-            ga[(v + 8) & 15] = (uint8_t)ring;                                   // lanes that do not own the cell hit the "empty" byte
-            const M mpos = (M)(long long)((0 - v) >> 31), mneg = (M)(long long)(v >> 31); // all ones where v > 0 / v < 0
-            N |= ((M)1 << ring) & mpos;
-            P |= ((M)1 << ring) & mneg;
-        }
+        for (int j = 0; j < T; j++) { const int c = i * T + j; if (c < S * S && (T == 1 || sub == j)) ring = G.ring_of_rm[S * S - 1 - c]; }
+        ga[(v[i] + 8) & 15] = (uint8_t)ring;                                        // an empty (or out-of-range) cell hits the spare byte
+        const M mpos = (M)(long long)((0 - v[i]) >> 31), mneg = (M)(long long)(v[i] >> 31); // all ones where v > 0 / v < 0
+        N |= ((M)1 << ring) & mpos;
+        P |= ((M)1 << ring) & mneg;
     }
     __builtin_amdgcn_wave_barrier();
     const uint4 x = *(const uint4 *)ga;
@@ -481,12 +510,8 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
             }
             else if (writer) B.done[game] = 1;
         }
-        d3_encode<S, T>(Tb, s, sub, mine);
-        if (writer) {
-            *rng_hdr_ptr(B.rng, game) = r.header();
-            B.dice[game] = (int8_t)dice;
-        }
     }
+    uint16_t ract_word = 0;
     if (live && writer && B.ract) {
         // RandomAgent.predict on the post-step observation (the agent is the canonical BOTTOM_RIGHT side)
         int f = 0, d = 0;
@@ -501,8 +526,17 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
                 d = slot < 3 ? slot : slot - 3;
             }
         }
-        ((uint16_t *)B.ract)[game] = (uint16_t)((uint8_t)f | ((uint16_t)(uint8_t)d << 8));
+        ract_word = (uint16_t)((uint8_t)f | ((uint16_t)(uint8_t)d << 8));
     }
+    // table reads above, board bytes below: the compiler cannot move an LDS read across an LDS write it cannot tell apart
+    if (active) {
+        d3_encode<S, T>(Tb, s, sub, mine);
+        if (writer) {
+            *rng_hdr_ptr(B.rng, game) = r.header();
+            B.dice[game] = (int8_t)dice;
+        }
+    }
+    if (live && writer && B.ract) ((uint16_t *)B.ract)[game] = ract_word;
     if (live && writer) {
         B.reward[game] = reward; B.terminated[game] = (uint8_t)term;
         B.truncated[game] = (uint8_t)trunc; B.info[game] = (uint8_t)info;
