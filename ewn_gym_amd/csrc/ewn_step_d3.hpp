@@ -116,7 +116,11 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
     // my share of the replier's (cube, dir) moves; they never change during the search
     M rset[KPT][3], rclr[KPT];
     int rnk[KPT];
-    u32 legal = 0, hits_origin = 0, mine_alive = 0;
+    // per reply, root-invariant: rank index = ((ix + iy) & keep) | fixed.  An illegal reply reads rank[0] = 1023 ("no such
+    // reply"), a reply onto the origin rank[1] = 1 (-10, envs/minimax_ewn.py:45-47).  The exceptions steer the INDEX instead
+    // of selecting the loaded value: a select on a loaded value makes the compiler branch around the LDS reads.
+    u32 keep[KPT][3], fixed[KPT][3];
+    u32 mine_alive = 0;
     #pragma unroll
     for (int i = 0; i < KPT; i++) {
         const int k = sub + T * i;          // may be >= 6 for the last slot when 6 % T != 0: byte 6/7 = a cube that is off the board
@@ -129,8 +133,9 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
             const int dn = Tb->nbn[d][rb];
             const bool ok = dn != 255;
             rset[i][d] = ok ? (one << dn) : (M)0;
-            legal |= (ok ? 1u : 0u) << (i * 3 + d);
-            hits_origin |= ((ok && dn == Tb->ri_origin) ? 1u : 0u) << (i * 3 + d);
+            const bool home = ok && dn == Tb->ri_origin;
+            keep[i][d] = (ok && !home) ? ~0u : 0u;
+            fixed[i][d] = home ? 1u : 0u;
         }
     }
 
@@ -164,31 +169,25 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
         constexpr int CH = KPT > 3 ? 3 : KPT; // cubes staged together: 9 leaves in flight; more only costs registers (T = 1: 186 VGPRs)
         #pragma unroll
         for (int i0 = 0; i0 < KPT; i0 += CH) {
-            u32 lx[CH][3], ly[CH][3], keep[CH][3], fixed[CH][3], a[CH][3];
+            u32 lx[CH][3], ly[CH][3], am[CH], a[CH][3];
             #pragma unroll
             for (int ii = 0; ii < CH; ii++) {
                 const int i = i0 + ii;
-                const bool alive1 = ((mine_alive >> i) & 1u) && rnk[i] != dest;
+                am[ii] = (((mine_alive >> i) & 1u) && rnk[i] != dest) ? ~0u : 0u; // my cube is still there after the root move
                 const M Nk = N1 & rclr[i];
                 #pragma unroll
                 for (int d = 0; d < 3; d++) {
                     const M N2 = Nk | rset[i][d];
                     const M P2 = P1 & ~rset[i][d];
-                    lx[ii][d] = Tb->lutx[clz_m(P2)] + popc_m(P2) * IXN;
+                    lx[ii][d] = Tb->lutx[clz_m(P2)] + popc_m(P2) * IXN; // P2 == 0 (last cube captured): row 0 of rank[] holds 1 (-10)
                     ly[ii][d] = Tb->luty[clz_m(N2)] + popc_m(N2);
-                    // rank[0] = 1023 ("no such reply"), rank[1] = 1 (-10: envs/minimax_ewn.py:45-47).  The exceptions steer the
-                    // INDEX with and/or instead of selecting the loaded value: a select on a loaded value makes the compiler
-                    // branch around the LDS reads
-                    const bool absent = !(alive1 && ((legal >> (i * 3 + d)) & 1u));
-                    const bool lost = P2 == 0 || ((hits_origin >> (i * 3 + d)) & 1u);
-                    keep[ii][d] = (absent || lost) ? 0u : ~0u; fixed[ii][d] = absent ? 0u : (lost ? 1u : 0u);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
             #pragma unroll
             for (int ii = 0; ii < CH; ii++) {
                 #pragma unroll
-                for (int d = 0; d < 3; d++) a[ii][d] = Tb->rank[((lx[ii][d] + ly[ii][d]) & keep[ii][d]) | fixed[ii][d]];
+                for (int d = 0; d < 3; d++) a[ii][d] = Tb->rank[(((lx[ii][d] + ly[ii][d]) & keep[i0 + ii][d]) | fixed[i0 + ii][d]) & am[ii]];
             }
             __builtin_amdgcn_sched_barrier(0);
             u32 p1[CH], p2[CH];
