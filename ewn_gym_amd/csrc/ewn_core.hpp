@@ -305,6 +305,12 @@ struct PhiloxStream {
     u32 b0, b1, b2, b3;
     u32 have; // block index + 1 currently cached (0 = none)
     EWN_DEV void init(u32 c1_, u32 c2_, u32 c3_, u64 key, u32 n_) { c1 = c1_; c2 = c2_; c3 = c3_; k0 = (u32)key; k1 = (u32)(key >> 32); n = n_; have = 0; b0 = b1 = b2 = b3 = 0; }
+    // compute the block the next draw comes from now (e.g. while a load is in flight); next() will find it cached
+    EWN_DEV void prime()
+    {
+        const u32 b = n >> 2;
+        if (have != b + 1) { u32 o[4]; philox4x32_10(b, c1, c2, c3, k0, k1, o); b0 = o[0]; b1 = o[1]; b2 = o[2]; b3 = o[3]; have = b + 1; }
+    }
     EWN_DEV u32 next()
     {
         const u32 b = n >> 2;

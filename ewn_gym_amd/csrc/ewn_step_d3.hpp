@@ -441,8 +441,16 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
         const uint16_t a2 = ((const uint16_t *)B.actions)[game];
         aflag = (int8_t)(a2 & 0xff); adir = (int8_t)(a2 >> 8);
     }
-    block_copy_in(lds, B.board + (size_t)g0 * CELLS, ng * CELLS);
-    __syncthreads();
+    // boards: request them now, put them into LDS after the RNG work below, whose ~200 issue slots (one Philox block) then
+    // run while the data is on its way instead of in the agent half
+    const int8_t *gsrc = B.board + (size_t)g0 * CELLS;
+    const int nbytes = ng * CELLS, nq = nbytes >> 4;
+    const bool split = (((uintptr_t)gsrc | (uintptr_t)nbytes) & 15) == 0 && nq <= 2 * D3_BS;
+    uint4 st0 = make_uint4(0u, 0u, 0u, 0u), st1 = st0;
+    if (split) {
+        if ((int)threadIdx.x < nq) st0 = ((const uint4 *)gsrc)[threadIdx.x];
+        if ((int)threadIdx.x + D3_BS < nq) st1 = ((const uint4 *)gsrc)[threadIdx.x + D3_BS];
+    }
 
     int8_t *mine = lds + gl * CELLS, *mine_t = lds_t + gl * CELLS;
     double reward = 0.0;
@@ -454,6 +462,12 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
     [[maybe_unused]] u32 epoch = 0;
     if constexpr (RNGK == 0) { if (live) { r.prefetch_next(B.rng, c.N, game); epoch = *rng_epoch_ptr(B.rng, c.N, c.W, game); } }
     r.begin_step();
+    if constexpr (RNGK == 1) r.ps.prime();
+    if (split) {
+        if ((int)threadIdx.x < nq) ((uint4 *)lds)[threadIdx.x] = st0;
+        if ((int)threadIdx.x + D3_BS < nq) ((uint4 *)lds)[threadIdx.x + D3_BS] = st1;
+    } else block_copy_in(lds, gsrc, nbytes);
+    __syncthreads();
     d3_decode<S, T>(live ? mine : lds, sub, garr + gl * 16, s); // every lane takes part (DPP combine); non-live lanes read game 0 of the block
     const bool active = live && !frozen;
     bool reply = false;

@@ -11,7 +11,8 @@ stamp='''#define STAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0
 '''
 n0=s.count("STAMP(")
 s=s.replace("template <int S, int T, int OPP, int RNGK>\n__global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)\n{", stamp+"template <int S, int T, int OPP, int RNGK>\n__global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)\n{\n    unsigned long long stamps[8]; STAMP(0);")
-s=s.replace("    block_copy_in(lds, B.board + (size_t)g0 * CELLS, ng * CELLS);\n    __syncthreads();\n\n    int8_t *mine","    STAMP(1);\n    block_copy_in(lds, B.board + (size_t)g0 * CELLS, ng * CELLS);\n    __syncthreads();\n    STAMP(2);\n\n    int8_t *mine")
+s=s.replace("    const int8_t *gsrc = B.board + (size_t)g0 * CELLS;","    STAMP(1);\n    const int8_t *gsrc = B.board + (size_t)g0 * CELLS;")
+s=s.replace("    } else block_copy_in(lds, gsrc, nbytes);\n    __syncthreads();\n","    } else block_copy_in(lds, gsrc, nbytes);\n    __syncthreads();\n    STAMP(2);\n")
 s=s.replace("    const bool active = live && !frozen;","    STAMP(7);\n    const bool active = live && !frozen;")
 s=s.replace("    int oflag = 0, odir = 0;\n    if constexpr (OPP == 0) d3_search<S, T>(Tb, s, dice, sub, oflag, odir);","    STAMP(3);\n    int oflag = 0, odir = 0;\n    if constexpr (OPP == 0) d3_search<S, T>(Tb, s, dice, sub, oflag, odir);\n    STAMP(4);")
 s=s.replace("    __syncthreads();\n    block_copy_out(B.board + (size_t)g0 * CELLS, lds, ng * CELLS);\n    if (B.tboard) block_copy_out(B.tboard + (size_t)g0 * CELLS, lds_t, ng * CELLS);\n","    STAMP(5);\n    __syncthreads();\n    block_copy_out(B.board + (size_t)g0 * CELLS, lds, ng * CELLS);\n    STAMP(6);\n    if (threadIdx.x == 0 && B.tboard) for (int i = 0; i < 8; i++) ((unsigned long long *)B.tboard)[blockIdx.x * 8 + i] = stamps[i];\n")
