@@ -67,6 +67,10 @@ template <> struct MaskOf<8> { typedef u64 type; };
 
 EWN_DEV int clz_m(u32 m) { return __clz((int)m); }       // 32 for m == 0
 EWN_DEV int clz_m(u64 m) { return __clzll((long long)m); } // 64 for m == 0
+// the same without the clamp for a mask known to be non-zero wherever the result matters (v_ffbh gives -1 for 0: the table
+// read that follows then lands two bytes in front of the table, inside LDS, and its value is masked off by the caller)
+EWN_DEV int clz_nz(u32 m) { return __builtin_clz(m); }
+EWN_DEV int clz_nz(u64 m) { return __builtin_clzll(m); }
 EWN_DEV int popc_m(u32 m) { return __popc(m); }
 EWN_DEV int popc_m(u64 m) { return __popcll(m); }
 

@@ -180,7 +180,7 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
                     const M N2 = Nk | rset[i][d];
                     const M P2 = P1 & ~rset[i][d];
                     lx[ii][d] = Tb->lutx[clz_m(P2)] + popc_m(P2) * IXN; // P2 == 0 (last cube captured): row 0 of rank[] holds 1 (-10)
-                    ly[ii][d] = Tb->luty[clz_m(N2)] + popc_m(N2);
+                    ly[ii][d] = Tb->luty[clz_nz(N2)] + popc_m(N2);       // N2 holds the moved cube unless the reply is absent (index masked)
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
