@@ -515,3 +515,20 @@ def test_one_lane_per_game_variant_at_131072_lanes(ea):
             for k in range(6):
                 x, o = cpu(res[k][lo:hi]), ores[k]
                 assert np.array_equal(bits(x) if k == 2 else x, bits(o) if k == 2 else o), (S, t, k)
+
+
+def test_ragged_and_empty_inputs(ea):
+    """Edge shapes: no observations, one lane, lane counts that do not fill a block or a wave, out-of-range dice in queries."""
+    e = np.zeros((0, 5, 5), np.int8)
+    assert tuple(ea.predict_minimax(e, np.zeros(0, np.int8), 3)[0].shape) == (0, 2)
+    assert tuple(ea.predict_mcts(e, np.zeros(0, np.int8), num_simulations=4, num_env_copies=1)[0].shape) == (0, 2)
+    assert tuple(ea.playout_wins(e, first_player=1, n_sims=8).shape) == (0,)
+    assert tuple(ea.evaluate(e).shape) == (0,)
+    for N in (1, 63, 257, 1000):
+        for opp, kw in (("random", {}), ("minimax", {"max_depth": 3}), ("mcts", {"num_simulations": 2, "num_env_copies": 2})):
+            _lockstep(ea, N, 6, seed0=N, opponent_policy=opp, rng="philox", philox_key=N, **kw)
+    # a dice value the game cannot produce (0, 7) must not fault: the stateless policies answer (-1, -1) for it
+    b, _ = _random_positions(5, 3, 64, 321)
+    for dv in (0, 7):
+        acts, _ = ea.predict_minimax(b, np.full(64, dv, np.int8), 3)
+        assert (cpu(acts) == -1).all()
