@@ -178,7 +178,8 @@ int ewn_apply_action(int board_size, int cube_layer, int M, const int8_t *boards
 
 /* MinimaxEnv.simulate (envs/minimax_ewn.py:215-238), the 'sim_winrate' heuristic: n_sims uniformly random playouts
  * from each position, `first_player` (1/2) moving first; wins [M] = playouts TOP_LEFT won.  Statistical parity only
- * (the reference draws from an unseeded Python `random`). */
+ * (the reference draws from an unseeded Python `random`); randomness as in ewn_predict_mcts with block {0, m, 0, 'SIMU'}
+ * and playout number r. */
 int ewn_playout_wins(int board_size, int cube_layer, int M, const int8_t *boards, int first_player, int n_sims,
                      uint64_t key, int32_t *wins, void *stream);
 
@@ -199,7 +200,10 @@ int ewn_predict_random(int board_size, int cube_layer, int M, const int8_t *boar
 
 /* MctsAgent.predict (classical_policies/mcts.py:102-106, flat Monte-Carlo :47-69, rollouts :21-45).
  * wins [M][6] int32 is REQUIRED scratch/output (win count per root move, -1 = no such move).
- * obs_id [M] (NULL = 0..M-1) and key select the Philox rollout streams. */
+ * obs_id [M] (NULL = 0..M-1) and key select the rollout randomness: one Philox block {0, obs_id, 0, 'MCTS'} per observation
+ * gives a word; rollout r of root move i runs a 32-bit LCG started at fmix32(word + (i * total + r) * 0x9E3779B9), one draw
+ * per ply (dice and move index).  The result does not depend on how rollouts are distributed over lanes.  Statistical parity
+ * with the reference (never-seeded Python `random`, mcts.py:29-32); bit-exact with oracle/ewn_oracle.c, which mirrors it. */
 int ewn_predict_mcts(int board_size, int cube_layer, int M, const int8_t *boards, const int8_t *dice,
                      int num_simulations, int num_env_copies, uint64_t key, const uint32_t *obs_id, int8_t *actions,
                      int32_t *wins, void *stream);
