@@ -49,6 +49,7 @@ def parse():
                          "random_action output")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly from Python instead of replaying a hipGraph")
     ap.add_argument("--graph-steps", type=int, default=50, help="steps captured per graph")
+    ap.add_argument("--mt-window", type=int, default=0, help="MT19937-compat mode: precomputed outputs per episode window (0 = engine default)")
     ap.add_argument("--pipeline-groups", type=int, default=2,
                     help="also report (extra field, not `value`) the rate of the same lanes split into this many groups that step on "
                          "their own streams without a barrier between them; 0 = skip")
@@ -126,7 +127,7 @@ def main():
     env = ea.VecEWN(N, board_size=args.board_size, cube_layer=args.cube_layer, opponent_policy=args.opponent,
                     max_depth=args.max_depth, rng=args.rng, autoreset=True, lane_offset=lo, seed_stride=N * world,
                     philox_key=2024, num_simulations=args.num_simulations, num_env_copies=args.num_env_copies,
-                    want_random_action=not args.separate_agent_kernel)
+                    want_random_action=not args.separate_agent_kernel, mt_window=args.mt_window)
     from ewn_gym_amd.sharding import lane_seeds
     env.reset(seeds=lane_seeds(lo, hi).cuda())  # reference default seed 9487 + global lane id
     counter = torch.zeros((), dtype=torch.int32, device="cuda")  # device-side step index: lets the captured graph advance

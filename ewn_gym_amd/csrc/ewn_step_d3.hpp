@@ -300,6 +300,10 @@ struct D3Buf {
 };
 
 #define D3_BS 256
+#ifndef D3_REFILL_PRIO
+#define D3_REFILL_PRIO 3
+#define D3_STEP_PRIO 0
+#endif
 
 // real board bytes -> canonical ring state.  Real value v > 0 is the agent's cube v (canonical BOTTOM_RIGHT side),
 // v < 0 the opponent's cube |v| (canonical TOP_LEFT side); real cell c sits at canonical cell S*S-1-c, whose ring
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
             if ((int)blockIdx.x < c.refill_blocks) {
                 if (threadIdx.x < 64) {
                     // a latency-bound dependent chain that shares its SIMD with busy step waves: let it win arbitration
-                    __builtin_amdgcn_s_setprio(3);
+                    __builtin_amdgcn_s_setprio(D3_REFILL_PRIO);
                     const u32 *cnt = Q.cnt + (size_t)(phase ^ 1u) * Q.nb4;
                     // refill block j serves the regions of step blocks j, j + refill_blocks, ...
                     for (int sb = (int)blockIdx.x; sb < step_blocks; sb += c.refill_blocks) {
@@ -419,6 +423,7 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
             }
         }
     }
+    if constexpr (RNGK == 0) { if (D3_STEP_PRIO) __builtin_amdgcn_s_setprio(D3_STEP_PRIO); }
     int8_t *lds_t = lds + GPB * CELLS;
     int8_t *tb = lds + ((2 * GPB * CELLS + 15) & ~15);
     tables_to_lds<FAST_TAB_BYTES(S)>(tb, (const int8_t *)B.tables); // LDS-DMA, waited for at the barrier

@@ -15,11 +15,11 @@ env.sample_legal_actions(31, out=acts)
 env.step(acts)
 torch.cuda.synchronize()
 T = int(os.environ.get("EWN_D3_T", "4"))
-nb = N * T // 256 + (256 if (len(sys.argv) > 1 and sys.argv[1] == 'mt19937') else 0)
-st = dbg[:nb * 64].view(torch.int64).cpu().numpy().reshape(nb, 8)
-if len(sys.argv) > 1 and sys.argv[1] == 'mt19937':
-    st = st[256:]   # the first 256 blocks of the MT launch are refill blocks
-    nb -= 256
+nb = N * T // 256
+mt = len(sys.argv) > 1 and sys.argv[1] == 'mt19937'
+st = dbg[:(2 * nb if mt else nb) * 64].view(torch.int64).cpu().numpy().reshape(-1, 8)
+if mt:
+    st = st[nb:]   # the first half of the MT launch's blocks are refill blocks (one per step block)
 order = [0, 1, 2, 7, 3, 4, 5, 6]
 st = st[:, order]
 d = np.diff(st, axis=1)
