@@ -337,8 +337,9 @@ EWN_DEV void d3_decode(const int8_t *b, int sub, uint8_t *ga, RState<S> &s)
     __builtin_amdgcn_wave_barrier();
     const uint4 x = *(const uint4 *)ga;
     __builtin_amdgcn_wave_barrier();
-    s.posN = ((((u64)x.w << 32) | x.z) >> 8) | (0x40ull << 56);                              // bytes 9..14 -> 0..5
-    s.posP = ((u64)__builtin_bswap32(x.x) << 32) | __builtin_bswap32(x.y);                   // bytes 7..2 -> 0..5, 1..0 -> 6..7
+    // bytes 6 and 7 are forced "off the board" whatever a malformed board (|v| > 6) scattered there
+    s.posN = ((((u64)x.w << 32) | x.z) >> 8) | PK_PADS;                                      // bytes 9..14 -> 0..5
+    s.posP = (((u64)__builtin_bswap32(x.x) << 32) | __builtin_bswap32(x.y)) | PK_PADS;       // bytes 7..2 -> 0..5, 1..0 -> 6..7
     if constexpr (T >= 2) {
         #define D3_OR64(x, ctrl) x |= ((u64)dpp_u32<ctrl>((u32)(x >> 32)) << 32) | dpp_u32<ctrl>((u32)x)
         #define D3_ORM(x, ctrl) do { if constexpr (sizeof(M) == 4) x |= (M)dpp_u32<ctrl>((u32)x); else { u64 t_ = (u64)x; D3_OR64(t_, ctrl); x = (M)t_; } } while (0)
