@@ -532,3 +532,28 @@ def test_ragged_and_empty_inputs(ea):
     for dv in (0, 7):
         acts, _ = ea.predict_minimax(b, np.full(64, dv, np.int8), 3)
         assert (cpu(acts) == -1).all()
+
+
+def test_mt19937_windows_at_scale(ea):
+    """MT19937-compat dice with the T = 2 kernel instance and one refill block per step block: enough steps for every lane to
+    rotate through its three windows several times; a slice against the oracle (numpy's stream)."""
+    N, T = 40000, 45
+    kw = dict(opponent_policy="minimax", max_depth=3, rng="mt19937", autoreset=True, seed_stride=N)
+    seeds = (np.arange(N, dtype=np.uint64) * 5 + 11).astype(np.uint32)
+    env = ea.VecEWN(N, **kw)
+    env.reset(seeds=seeds)
+    lo, hi = 33333, 33333 + 320
+    orc = po.OracleVecEnv(hi - lo, opponent="minimax", max_depth=3, rng="mt19937", autoreset=True, seed_stride=N, lane_offset=lo)
+    orc.reset(seeds=seeds[lo:hi])
+    nterm = 0
+    for t in range(T):
+        a = env.sample_legal_actions(t).clone()
+        oa = orc.sample_legal_actions(t)
+        assert np.array_equal(cpu(a[lo:hi]), oa)
+        res = env.step(a)
+        ores = orc.step(oa)
+        for k in range(6):
+            x, o = cpu(res[k][lo:hi]), ores[k]
+            assert np.array_equal(bits(x) if k == 2 else x, bits(o) if k == 2 else o), (t, k)
+        nterm += int(ores[3].sum())
+    assert nterm > 4 * (hi - lo)   # every lane of the slice has gone through several episodes
