@@ -557,3 +557,25 @@ def test_mt19937_windows_at_scale(ea):
             assert np.array_equal(bits(x) if k == 2 else x, bits(o) if k == 2 else o), (t, k)
         nterm += int(ores[3].sum())
     assert nterm > 4 * (hi - lo)   # every lane of the slice has gone through several episodes
+
+
+def test_g12_maximum_board_size(ea, golden):
+    """8x8 (the largest supported board) against vectors produced by the reference itself: heuristics, depth 1-3 searches
+    (depth 3 'hybrid' through the table-driven kernel), trajectories vs Random and vs minimax(3)."""
+    g = golden("g12_maxboard.json")
+    S, L = g["S"], g["L"]
+    boards = np.array([r["board"] for r in g["eval"]], np.int8).reshape(-1, S, S)
+    for h in ("hybrid", "min_dist", "two_min_dist", "attk"):
+        vals = cpu(ea.evaluate(boards, h, cube_layer=L))
+        assert [float(v).hex() for v in vals] == [float.fromhex(r[h]).hex() for r in g["eval"]], h
+    recs = g["minimax"]
+    for key in sorted({k for r in recs for k in r["res"]}):
+        d, h = key.split("/")
+        acts, vals = ea.predict_minimax(np.array([r["board"] for r in recs], np.int8).reshape(-1, S, S), [r["dice"] for r in recs],
+                                        int(d), h, cube_layer=L)
+        acts, vals = cpu(acts), cpu(vals)
+        for i, r in enumerate(recs):
+            a0, a1, v = r["res"][key]
+            assert acts[i].tolist() == [a0, a1] and float(vals[i]).hex() == float.fromhex(v).hex(), (key, i)
+    _run_group(ea, [r for r in g["traj"] if r["opp"] == "random"], "random")
+    _run_group(ea, [r for r in g["traj"] if r["opp"] == "minimax"], "minimax", max_depth=3, heuristic="hybrid")

@@ -156,3 +156,30 @@ def test_g9_flat_monte_carlo_statistics(golden):
                 sigma = max(1e-9, (p * (1 - p) * (1 / r["n"] + 1 / nsim)) ** 0.5)
                 assert abs(p_ref - p_or) <= 5 * sigma + 1e-9, (S, i, j, p_ref, p_or)
             assert (wins[i, len(r["wins"]):] == -1).all()
+
+
+def test_g12_maximum_board_size(golden):
+    """8x8, the largest board this build supports: heuristics, depth 1-3 search results and full trajectories produced by the
+    reference (oracle/gen_golden_maxboard.py)."""
+    g = golden("g12_maxboard.json")
+    S, L = g["S"], g["L"]
+    boards = np.array([r["board"] for r in g["eval"]], np.int8).reshape(-1, S, S)
+    for h in ("hybrid", "min_dist", "two_min_dist", "attk"):
+        vals = po.evaluate(boards, h, cube_layer=L)
+        assert [float(v).hex() for v in vals] == [float.fromhex(r[h]).hex() for r in g["eval"]], h
+    recs = g["minimax"]
+    n = 0
+    for key in sorted({k for r in recs for k in r["res"]}):
+        d, h = key.split("/")
+        acts, vals, _ = po.predict_minimax(np.array([r["board"] for r in recs], np.int8).reshape(-1, S, S), [r["dice"] for r in recs],
+                                           int(d), h, cube_layer=L)
+        for i, r in enumerate(recs):
+            a0, a1, v = r["res"][key]
+            assert acts[i].tolist() == [a0, a1] and vals[i].hex() == float.fromhex(v).hex(), (key, i)
+            n += 1
+    assert n >= 400
+    for rec in g["traj"]:
+        if rec["opp"] == "random":
+            _check_traj(rec, "random")
+        else:
+            _check_traj(rec, "minimax", max_depth=rec["depth"], heuristic=rec["heuristic"])
