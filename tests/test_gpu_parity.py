@@ -579,3 +579,18 @@ def test_g12_maximum_board_size(ea, golden):
             assert acts[i].tolist() == [a0, a1] and float(vals[i]).hex() == float.fromhex(v).hex(), (key, i)
     _run_group(ea, [r for r in g["traj"] if r["opp"] == "random"], "random")
     _run_group(ea, [r for r in g["traj"] if r["opp"] == "minimax"], "minimax", max_depth=3, heuristic="hybrid")
+
+
+def test_g13_cube_layers_4_and_5(ea, golden):
+    """cube_layer 4 / 5 (10 / 15 cubes a side) against vectors produced by the reference: searches and minimax-opponent trajectories"""
+    for grp in golden("g13_layers.json"):
+        S, L, recs = grp["S"], grp["L"], grp["minimax"]
+        for key in sorted({k for r in recs for k in r["res"]}):
+            d, h = key.split("/")
+            acts, vals = ea.predict_minimax(np.array([r["board"] for r in recs], np.int8).reshape(-1, S, S), [r["dice"] for r in recs],
+                                            int(d), h, cube_layer=L)
+            acts, vals = cpu(acts), cpu(vals)
+            for i, r in enumerate(recs):
+                a0, a1, v = r["res"][key]
+                assert acts[i].tolist() == [a0, a1] and float(vals[i]).hex() == float.fromhex(v).hex(), (S, L, key, i)
+        _run_group(ea, grp["traj"], "minimax", max_depth=2, heuristic="hybrid")

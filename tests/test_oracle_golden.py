@@ -183,3 +183,22 @@ def test_g12_maximum_board_size(golden):
             _check_traj(rec, "random")
         else:
             _check_traj(rec, "minimax", max_depth=rec["depth"], heuristic=rec["heuristic"])
+
+
+def test_g13_cube_layers_4_and_5(golden):
+    """10 and 15 cubes a side (two-word position state in the HIP code; the search's dice loop still runs 1..6 as upstream):
+    search results and minimax-opponent trajectories produced by the reference (oracle/gen_golden_layers.py)."""
+    n = 0
+    for grp in golden("g13_layers.json"):
+        S, L, recs = grp["S"], grp["L"], grp["minimax"]
+        for key in sorted({k for r in recs for k in r["res"]}):
+            d, h = key.split("/")
+            acts, vals, _ = po.predict_minimax(np.array([r["board"] for r in recs], np.int8).reshape(-1, S, S), [r["dice"] for r in recs],
+                                               int(d), h, cube_layer=L)
+            for i, r in enumerate(recs):
+                a0, a1, v = r["res"][key]
+                assert acts[i].tolist() == [a0, a1] and vals[i].hex() == float.fromhex(v).hex(), (S, L, key, i)
+                n += 1
+        for rec in grp["traj"]:
+            _check_traj(rec, "minimax", max_depth=rec["depth"], heuristic=rec["heuristic"])
+    assert n >= 300
