@@ -79,8 +79,11 @@ EWN_DEV int popc_m(u64 m) { return __popcll(m); }
 #include <cstring>
 #include <vector>
 
+// variant 0: max_depth 3 (a leaf is evaluate()).  variant 1: max_depth 4, where the search goes one chance node and one
+// depth-0 max node further before evaluating (classical_policies/minimax.py:19-73): a non-terminal leaf is then
+// sum over six dice of evaluate()/6, added in order -- the same tables with that value in place of evaluate().
 template <int S>
-static int build_fast_tables(FastTab<S> *T)
+static int build_fast_tables(FastTab<S> *T, int variant = 0)
 {
     constexpr int IXN = FastTab<S>::IXN;
     memset(T, 0, sizeof(*T));
@@ -157,7 +160,8 @@ static int build_fast_tables(FastTab<S> *T)
             volatile double x = (double)(tp + 1) * rp, y = (double)(tn + 1) * rn_;
             volatile double s0 = 0.0 + x;
             volatile double s1 = s0 - y;
-            const double ev = s1;
+            double ev = s1;
+            if (variant == 1) { volatile double sixth = ev / 6.0, acc = 0.0; for (int d = 0; d < 6; d++) acc = acc + sixth; ev = acc; }
             e[(size_t)(tp * 8 + np_) * IXN + (tn * 8 + nn)] = ev;
             all.push_back(ev);
         }

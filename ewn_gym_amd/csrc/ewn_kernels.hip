@@ -310,7 +310,7 @@ __global__ __launch_bounds__(BS) void k_step(Geom g, KCfg c, KState st, const in
                 } else if (reply) {
                     if constexpr (FAST != 0) {
                         const GState<1> cst = canonicalize<1>(g, s);
-                        fast_d3<(FAST ? FAST : 5)>(ftab, cst, dice, oflag, odir);
+                        fast_d3<(FAST ? FAST : 5)>(ftab, cst, dice, c.depth, oflag, odir);
                     } else if (PHASE == 0) {
                         if (c.opp == EWN_OPP_RANDOM) policy_random<NW>(g, s, dice, r, oflag, odir);
                         else policy_minimax_rt<NW>(g, s, dice, c.depth, c.heur, oflag, odir);
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(BS) void k_predict_minimax(Geom g, int M, const int
 }
 
 template <int S>
-__global__ __launch_bounds__(BS) void k_predict_minimax_fast(Geom g, int M, const int8_t *boards, const int8_t *dice,
+__global__ __launch_bounds__(BS) void k_predict_minimax_fast(Geom g, int M, const int8_t *boards, const int8_t *dice, int depth,
                                                              int8_t *actions, double *values, const void *tables)
 {
     extern __shared__ __attribute__((aligned(16))) int8_t lds[];
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(BS) void k_predict_minimax_fast(Geom g, int M, cons
     const int dc = dice[m];
     if (s.aliveP != 0 && dc >= 1 && dc <= g.CN) {
         if (is_win<1>(g, s)) v = evaluate<1>(g, s, EWN_H_HYBRID);
-        else v = fast_d3<S>(T, s, dc, f, d);
+        else v = fast_d3<S>(T, s, dc, depth, f, d);
     }
     actions[2 * m] = (int8_t)f; actions[2 * m + 1] = (int8_t)d;
     if (values) values[m] = v;
@@ -800,7 +800,7 @@ int64_t ewn_tables_bytes(int board_size, int cube_layer)
 {
     Geom g;
     if (!make_geom(board_size, cube_layer, g)) return 0;
-    return fast_tables_bytes(board_size, cube_layer);
+    return 2 * fast_tables_bytes(board_size, cube_layer); // two images: max_depth <= 3, then max_depth 4 (ewn_fast.hpp)
 }
 
 int ewn_build_tables(int board_size, int cube_layer, void *host_out)
@@ -809,10 +809,10 @@ int ewn_build_tables(int board_size, int cube_layer, void *host_out)
     if (ewn_tables_bytes(board_size, cube_layer) <= 0) return EWN_EUNSUPPORTED;
     int rc = -1;
     switch (board_size) {
-    case 5: rc = build_fast_tables<5>((FastTab<5> *)host_out); break;
-    case 6: rc = build_fast_tables<6>((FastTab<6> *)host_out); break;
-    case 7: rc = build_fast_tables<7>((FastTab<7> *)host_out); break;
-    case 8: rc = build_fast_tables<8>((FastTab<8> *)host_out); break;
+    case 5: rc = build_fast_tables<5>((FastTab<5> *)host_out, 0) | build_fast_tables<5>((FastTab<5> *)((int8_t *)host_out + FAST_TAB_BYTES(5)), 1); break;
+    case 6: rc = build_fast_tables<6>((FastTab<6> *)host_out, 0) | build_fast_tables<6>((FastTab<6> *)((int8_t *)host_out + FAST_TAB_BYTES(6)), 1); break;
+    case 7: rc = build_fast_tables<7>((FastTab<7> *)host_out, 0) | build_fast_tables<7>((FastTab<7> *)((int8_t *)host_out + FAST_TAB_BYTES(7)), 1); break;
+    case 8: rc = build_fast_tables<8>((FastTab<8> *)host_out, 0) | build_fast_tables<8>((FastTab<8> *)((int8_t *)host_out + FAST_TAB_BYTES(8)), 1); break;
     }
     return rc == 0 ? EWN_OK : EWN_EUNSUPPORTED;
 }
@@ -931,11 +931,12 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
     const size_t lds = (size_t)2 * BS * g.cells;
     if (cfg->opponent_kind != EWN_OPP_MCTS) {
         const bool fast = st->tables && fast_tables_bytes(g.S, g.L) > 0 && cfg->opponent_kind == EWN_OPP_MINIMAX &&
-                          cfg->max_depth == 3 && cfg->heuristic == EWN_H_HYBRID;
+                          cfg->max_depth <= 4 && cfg->heuristic == EWN_H_HYBRID;
         const bool lean_random = st->tables && fast_tables_bytes(g.S, g.L) > 0 && cfg->opponent_kind == EWN_OPP_RANDOM;
+        if (fast && cfg->max_depth == 4) ks.tables = (const int8_t *)st->tables + fast_tables_bytes(g.S, g.L); // the max_depth-4 image
         if ((fast || lean_random) && !cfg->shaped && d3_threads_per_game(k.N) > 0) {
             // the lean fused kernel: canonical ring space end to end, T lanes per game (ewn_step_d3.hpp)
-            const int T = lean_random ? 1 : d3_threads_per_game(k.N);
+            const int T = (lean_random || cfg->max_depth < 3) ? 1 : d3_threads_per_game(k.N); // no leaves to share below depth 3
             const int gpb0 = D3_BS / T, step_blocks = (k.N + gpb0 - 1) / gpb0;
             // MT kind with auto-reset: window refills are extra blocks of the same launch (needs the caller's scratch)
             const bool fused_refill = refill && scratch != nullptr;
@@ -944,8 +945,8 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
             // step role's ~45 k.  Measured at 65 536 lanes: 256 refill blocks (two regions each, two chains back to back) 38.4 us
             // per launch, 512 blocks 26.5 us.
             const int refill_blocks = fused_refill ? step_blocks : 0;
-            D3Cfg dc = { k.N, k.rng_kind, k.autoreset, k.lane_offset, refill_blocks, k.seed_stride, k.W, k.reward, k.key };
-            D3Buf db = { st->board, st->dice, st->done, st->rng, st->tables, actions, out->reward, out->terminated,
+            D3Cfg dc = { k.N, k.rng_kind, k.autoreset, k.lane_offset, k.depth, refill_blocks, k.seed_stride, k.W, k.reward, k.key };
+            D3Buf db = { st->board, st->dice, st->done, st->rng, ks.tables, actions, out->reward, out->terminated,
                          out->truncated, out->info, out->terminal_board, out->terminal_dice, out->random_action,
                          fused_refill ? scratch : nullptr };
             const int gpb = gpb0;
@@ -1087,12 +1088,13 @@ int ewn_predict_minimax(int board_size, int cube_layer, int M, const int8_t *boa
     if (M == 0) return EWN_OK;
     if (!dice || !actions) return EWN_ENULL;
     hipStream_t s = (hipStream_t)stream;
-    if (tables && fast_tables_bytes(g.S, g.L) > 0 && max_depth == 3 && heuristic == EWN_H_HYBRID) {
+    if (tables && fast_tables_bytes(g.S, g.L) > 0 && max_depth <= 4 && heuristic == EWN_H_HYBRID) {
+        if (max_depth == 4) tables = (const int8_t *)tables + fast_tables_bytes(g.S, g.L); // the max_depth-4 image
         switch (g.S) {
-        case 5: k_predict_minimax_fast<5><<<GRID(M), BS, FAST_TAB_BYTES(5), s>>>(g, M, boards, dice, actions, values, tables); break;
-        case 6: k_predict_minimax_fast<6><<<GRID(M), BS, FAST_TAB_BYTES(6), s>>>(g, M, boards, dice, actions, values, tables); break;
-        case 7: k_predict_minimax_fast<7><<<GRID(M), BS, FAST_TAB_BYTES(7), s>>>(g, M, boards, dice, actions, values, tables); break;
-        default: k_predict_minimax_fast<8><<<GRID(M), BS, FAST_TAB_BYTES(8), s>>>(g, M, boards, dice, actions, values, tables); break;
+        case 5: k_predict_minimax_fast<5><<<GRID(M), BS, FAST_TAB_BYTES(5), s>>>(g, M, boards, dice, max_depth, actions, values, tables); break;
+        case 6: k_predict_minimax_fast<6><<<GRID(M), BS, FAST_TAB_BYTES(6), s>>>(g, M, boards, dice, max_depth, actions, values, tables); break;
+        case 7: k_predict_minimax_fast<7><<<GRID(M), BS, FAST_TAB_BYTES(7), s>>>(g, M, boards, dice, max_depth, actions, values, tables); break;
+        default: k_predict_minimax_fast<8><<<GRID(M), BS, FAST_TAB_BYTES(8), s>>>(g, M, boards, dice, max_depth, actions, values, tables); break;
         }
         return launch_status();
     }

@@ -106,12 +106,47 @@ EWN_DEV void rs_move(RState<S> &s, int k, int q)
 // Depth-3 hybrid search in ring space, shared by T lanes (sub = my index in the group).
 // Every lane of the group returns the same (value, action).
 template <int S, int T>
-__device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S> &c, int dice, int sub, int &bflag, int &bdir)
+__device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S> &c, int dice, int sub, int depth, int &bflag, int &bdir)
 {
     typedef typename MaskOf<S>::type M;
     constexpr int IXN = FastTab<S>::IXN;
     constexpr int KPT = 6 / T + (6 % T ? 1 : 0); // replier cubes / dice values per lane: k = sub + T*i
     const M one = 1;
+
+    // root slots: <= 2 cubes x 3 dirs in the reference's list order (envs/ewn.py:338-375)
+    const u32 rsel = pk_sel<S>(Tb, c.posP, dice), rpp = pk_pair(c.posP, rsel);
+    const int rb0 = (int)(rpp & 0xFFu), rb1 = (int)(rpp >> 8);
+    const bool have0 = !(rb0 & PK_OFF), have1 = !(rb1 & PK_OFF);
+    const int flag0 = (int)(rsel >> 15);
+    const int rp0 = rb0 & 63, rp1 = rb1 & 63;
+
+    double best = -__builtin_inf(); // alpha = max(alpha, best_val): the running best (root beta stays +inf)
+    bflag = 0; bdir = 0;
+
+    if (depth < 3) {
+        // max_depth 1 and 2 bottom out before the replier moves (classical_policies/minimax.py:19-73: every node, chance nodes
+        // included, spends one unit of depth): depth 1 evaluates the position after the root move at the chance node; depth 2
+        // at the six min nodes below it, i.e. evaluate()/6 summed six times in dice order.  Every lane of the group does all six roots.
+        #pragma unroll 1
+        for (int r = 0; r < 6; r++) {
+            const int slot = r >= 3 ? 1 : 0, dir = r - 3 * slot;
+            const int rp = slot == 0 ? rp0 : rp1;
+            const int dest = Tb->nbp[dir][rp];
+            const bool valid = (slot == 0 ? have0 : have1) && dest != 255;
+            const M bd = valid ? (one << dest) : (M)0;
+            const M P1 = (c.P & ~(one << rp)) | bd;
+            const M N1 = c.N & ~bd;
+            const bool term = dest == FastTab<S>::CELLS - 1 || N1 == 0; // win(B1): value 10 at any depth
+            const u32 rk = Tb->rank[Tb->lutx[clz_m(P1)] + popc_m(P1) * IXN + Tb->luty[clz_m(N1)] + popc_m(N1)];
+            const double e1 = Tb->val[rk], e6 = Tb->val6[rk];
+            double v = 0.0;
+            #pragma unroll
+            for (int d = 0; d < 6; d++) v = v + e6;
+            v = term ? 10.0 : (depth == 1 ? e1 : v);
+            if (valid && v > best) { best = v; bflag = slot == 0 ? flag0 : 0; bdir = dir; }
+        }
+        return best;
+    }
 
     // my share of the replier's (cube, dir) moves; they never change during the search
     M rset[KPT][3], rclr[KPT];
@@ -138,16 +173,6 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
             fixed[i][d] = home ? 1u : 0u;
         }
     }
-
-    // root slots: <= 2 cubes x 3 dirs in the reference's list order (envs/ewn.py:338-375)
-    const u32 rsel = pk_sel<S>(Tb, c.posP, dice), rpp = pk_pair(c.posP, rsel);
-    const int rb0 = (int)(rpp & 0xFFu), rb1 = (int)(rpp >> 8);
-    const bool have0 = !(rb0 & PK_OFF), have1 = !(rb1 & PK_OFF);
-    const int flag0 = (int)(rsel >> 15);
-    const int rp0 = rb0 & 63, rp1 = rb1 & 63;
-
-    double best = -__builtin_inf(); // alpha = max(alpha, best_val): the running best (root beta stays +inf)
-    bflag = 0; bdir = 0;
 
     // a real loop, not unrolled: the body is ~450 instructions and six copies of it (plus the rest of the
     // kernel) do not fit the instruction cache shared by two CUs
@@ -267,7 +292,7 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
 
 // The same search from a row-major canonical GState (stateless predict kernel, generic step kernel's fast path)
 template <int S>
-__device__ __forceinline__ double fast_d3(const FastTab<S> *Tb, const GState<1> &c, int dice, int &bflag, int &bdir)
+__device__ __forceinline__ double fast_d3(const FastTab<S> *Tb, const GState<1> &c, int dice, int depth, int &bflag, int &bdir)
 {
     typedef typename MaskOf<S>::type M;
     RState<S> s;
@@ -281,13 +306,13 @@ __device__ __forceinline__ double fast_d3(const FastTab<S> *Tb, const GState<1> 
         s.posP |= (u64)(ap ? rp : PK_OFF) << (8 * k);
         s.posN |= (u64)(an ? rn : PK_OFF) << (8 * k);
     }
-    return d3_search<S, 1>(Tb, s, dice, 0, bflag, bdir);
+    return d3_search<S, 1>(Tb, s, dice, 0, depth, bflag, bdir);
 }
 
 // ---------------------------------------------------------------- the fused step kernel
 
 struct D3Cfg {
-    int N, rng_kind, autoreset, lane_offset, refill_blocks; // the first refill_blocks blocks of the grid rebuild MT windows (fused MT path), else 0
+    int N, rng_kind, autoreset, lane_offset, depth, refill_blocks; // depth: the opponent's max_depth (1..3); the first refill_blocks blocks of the grid rebuild MT windows (fused MT path), else 0
     u32 seed_stride, W;
     double reward;
     u64 key;
@@ -492,7 +517,7 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
     // the opponent's search: run by every lane (lanes without a pending reply compute on a harmless state),
     // so the DPP exchanges inside always see their partners
     int oflag = 0, odir = 0;
-    if constexpr (OPP == 0) d3_search<S, T>(Tb, s, dice, sub, oflag, odir);
+    if constexpr (OPP == 0) d3_search<S, T>(Tb, s, dice, sub, c.depth, oflag, odir);
     if (reply) {
         // opponent half, envs/ewn.py:464-486
         const u32 e = pk_sel<S>(Tb, s.posP, dice);
