@@ -67,10 +67,17 @@ template <> struct MaskOf<8> { typedef u64 type; };
 
 EWN_DEV int clz_m(u32 m) { return __clz((int)m); }       // 32 for m == 0
 EWN_DEV int clz_m(u64 m) { return __clzll((long long)m); } // 64 for m == 0
-// the same without the clamp for a mask known to be non-zero wherever the result matters (v_ffbh gives -1 for 0: the table
-// read that follows then lands two bytes in front of the table, inside LDS, and its value is masked off by the caller)
-EWN_DEV int clz_nz(u32 m) { return __builtin_clz(m); }
-EWN_DEV int clz_nz(u64 m) { return __builtin_clzll(m); }
+// the same without the clamp, for a mask that is non-zero wherever the result matters: the raw instruction answers -1 for 0 and the
+// table read that follows then lands two bytes in front of the table, inside LDS; the caller masks its value off.  Inline
+// assembly on purpose: __builtin_clz(0) is undefined behaviour the optimiser is free to act on.
+EWN_DEV int clz_nz(u32 m) { int r; asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(m)); return r; }
+EWN_DEV int clz_nz(u64 m)
+{
+    int hi, lo;
+    asm("v_ffbh_u32 %0, %1" : "=v"(hi) : "v"((u32)(m >> 32)));
+    asm("v_ffbh_u32 %0, %1" : "=v"(lo) : "v"((u32)m));
+    return (u32)(m >> 32) ? hi : 32 + lo;
+}
 EWN_DEV int popc_m(u32 m) { return __popc(m); }
 EWN_DEV int popc_m(u64 m) { return __popcll(m); }
 

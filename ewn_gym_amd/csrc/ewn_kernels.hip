@@ -74,6 +74,13 @@ __device__ __forceinline__ void tables_to_lds(int8_t *lds, const int8_t *g)
     }
 }
 
+// The LDS-DMA loads above are outstanding vector-memory operations of the wave that issued them; a barrier does not wait for
+// them.  Every wave must drain its own before the block barrier behind which OTHER waves read the chunks it fetched -- a
+// wave with no other load to wait for (all its lanes past the end of the batch, or simply faster) otherwise lets the rest
+// of the block read whatever the previous kernel left in that part of LDS (seen as wrong moves on one board size, only
+// after kernels for other board sizes had run on the same CUs).
+__device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 #include "ewn_step_d3.hpp"
 
 // ---------------------------------------------------------------- per-lane pieces
@@ -273,6 +280,7 @@ __global__ __launch_bounds__(BS) void k_step(Geom g, KCfg c, KState st, const in
     }
     block_copy_in(lds, st.board + (size_t)lane0 * g.cells, nl * g.cells);
     if (PHASE == 2 && out.tboard) block_copy_in(lds_t, out.tboard + (size_t)lane0 * g.cells, nl * g.cells);
+    if constexpr (FAST != 0) lds_dma_wait();
     __syncthreads();
     if (live) {
         int8_t *mine = lds + threadIdx.x * g.cells, *mine_t = lds_t + threadIdx.x * g.cells;
@@ -489,6 +497,7 @@ __global__ __launch_bounds__(BS) void k_predict_minimax_fast(Geom g, int M, cons
 {
     extern __shared__ __attribute__((aligned(16))) int8_t lds[];
     tables_to_lds<FAST_TAB_BYTES(S)>(lds, (const int8_t *)tables);
+    lds_dma_wait();
     __syncthreads();
     const FastTab<S> *T = (const FastTab<S> *)lds;
     const int m = blockIdx.x * BS + threadIdx.x;
@@ -824,11 +833,19 @@ int ewn_rng_words(const ewn_config *cfg)
     return rc ? rc : (int)k.rng_words;
 }
 
-// the lean kernel's MT refill hand-off (ewn_core.hpp MtQueue), sized for the smallest games-per-block (T = 4)
+// the lean kernel's MT refill hand-off (ewn_core.hpp MtQueue): ctrl[4] | cnt[2][nb4] | list[2][nblk][2 * games per block] x 16 B.
+// The layout depends on the lanes-per-game T the launch picks (games per block = 256 / T, nblk = ceil(N / games per block)), and
+// the rounding-up of nblk makes T = 1 the LARGEST for a small N (64 lanes: one block of 512 slots), so take the maximum over T.
+// (Sizing it for T = 4 only let a T = 1 launch on 64 lanes write 8 KB past the buffer -- into whatever tensor came next.)
 static int64_t mtq_bytes(int64_t N)
 {
-    const int64_t gpb = D3_BS / 4, nblk = (N + gpb - 1) / gpb, nb4 = (nblk + 3) / 4 * 4;
-    return 16 + 2 * nb4 * 4 + 2 * nblk * (2 * gpb) * 16;
+    int64_t best = 0;
+    for (int T = 1; T <= 4; T *= 2) {
+        const int64_t gpb = D3_BS / T, nblk = (N + gpb - 1) / gpb, nb4 = (nblk + 3) / 4 * 4;
+        const int64_t b = 16 + 2 * nb4 * 4 + 2 * nblk * (2 * gpb) * 16;
+        if (b > best) best = b;
+    }
+    return best;
 }
 
 int64_t ewn_step_scratch_bytes(const ewn_config *cfg)
@@ -931,12 +948,12 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
     const size_t lds = (size_t)2 * BS * g.cells;
     if (cfg->opponent_kind != EWN_OPP_MCTS) {
         const bool fast = st->tables && fast_tables_bytes(g.S, g.L) > 0 && cfg->opponent_kind == EWN_OPP_MINIMAX &&
-                          cfg->max_depth <= 4 && cfg->heuristic == EWN_H_HYBRID;
+                          cfg->max_depth <= 6 && cfg->heuristic == EWN_H_HYBRID;
         const bool lean_random = st->tables && fast_tables_bytes(g.S, g.L) > 0 && cfg->opponent_kind == EWN_OPP_RANDOM;
-        if (fast && cfg->max_depth == 4) ks.tables = (const int8_t *)st->tables + fast_tables_bytes(g.S, g.L); // the max_depth-4 image
+        if (fast && (cfg->max_depth == 4 || cfg->max_depth == 6)) ks.tables = (const int8_t *)st->tables + fast_tables_bytes(g.S, g.L); // the max_depth-4 image
         if ((fast || lean_random) && !cfg->shaped && d3_threads_per_game(k.N) > 0) {
             // the lean fused kernel: canonical ring space end to end, T lanes per game (ewn_step_d3.hpp)
-            const int T = (lean_random || cfg->max_depth < 3) ? 1 : d3_threads_per_game(k.N); // no leaves to share below depth 3
+            const int T = (lean_random || cfg->max_depth < 3 || cfg->max_depth > 4) ? 1 : d3_threads_per_game(k.N); // leaves are shared at depth 3-4 only
             const int gpb0 = D3_BS / T, step_blocks = (k.N + gpb0 - 1) / gpb0;
             // MT kind with auto-reset: window refills are extra blocks of the same launch (needs the caller's scratch)
             const bool fused_refill = refill && scratch != nullptr;
@@ -1088,8 +1105,8 @@ int ewn_predict_minimax(int board_size, int cube_layer, int M, const int8_t *boa
     if (M == 0) return EWN_OK;
     if (!dice || !actions) return EWN_ENULL;
     hipStream_t s = (hipStream_t)stream;
-    if (tables && fast_tables_bytes(g.S, g.L) > 0 && max_depth <= 4 && heuristic == EWN_H_HYBRID) {
-        if (max_depth == 4) tables = (const int8_t *)tables + fast_tables_bytes(g.S, g.L); // the max_depth-4 image
+    if (tables && fast_tables_bytes(g.S, g.L) > 0 && max_depth <= 6 && heuristic == EWN_H_HYBRID) {
+        if (max_depth == 4 || max_depth == 6) tables = (const int8_t *)tables + fast_tables_bytes(g.S, g.L); // the max_depth-4 image
         switch (g.S) {
         case 5: k_predict_minimax_fast<5><<<GRID(M), BS, FAST_TAB_BYTES(5), s>>>(g, M, boards, dice, max_depth, actions, values, tables); break;
         case 6: k_predict_minimax_fast<6><<<GRID(M), BS, FAST_TAB_BYTES(6), s>>>(g, M, boards, dice, max_depth, actions, values, tables); break;

@@ -103,6 +103,85 @@ EWN_DEV void rs_move(RState<S> &s, int k, int q)
     else { s.posN ^= mv; s.N = (s.N & ~(one << p)) | bq; s.P &= ~bq; }
 }
 
+// max_depth 5 (and, on the second table image, 6): the reference's loops as they stand (classical_policies/minimax.py:19-73) --
+// root move, chance, reply, chance, move, leaf -- with its alpha-beta windows passed through the chance nodes unchanged, on the
+// byte-per-cube state and the table leaf.  One lane per game; breaks diverge between the lanes of a wave, trip counts are
+// bounded (6^5 leaves).  A leaf is a rank lookup, an inner node a masked move: ~20x fewer instructions than the generic
+// template recursion on GState.
+template <int S>
+__device__ __forceinline__ double d5_search(const FastTab<S> *Tb, const RState<S> &c, int dice, int &bflag, int &bdir)
+{
+    typedef typename MaskOf<S>::type M;
+    constexpr int IXN = FastTab<S>::IXN;
+    const M one = 1;
+    const double inf = __builtin_inf();
+    const u32 rank10 = (u32)Tb->nv; // +10 is the largest value of the table
+    double best = -inf, alpha = -inf;
+    bflag = 0; bdir = 0;
+    const u32 e0 = pk_sel<S>(Tb, c.posP, dice), pp0 = pk_pair(c.posP, e0);
+    #pragma unroll 1
+    for (int r = 0; r < 6; r++) {
+        const int slot = r >= 3 ? 1 : 0, dir = r - 3 * slot;
+        const int cube = (int)((slot ? e0 >> 8 : e0) & 7u), rb = (int)((slot ? pp0 >> 8 : pp0) & 0xFFu);
+        const int dest = Tb->nbp[dir][rb];
+        if (dest == 255) continue;                     // no such cube (byte 6) or off the board
+        RState<S> s1 = c;
+        rs_move<S, true>(s1, cube, dest);
+        double v;
+        if (dest == FastTab<S>::CELLS - 1 || s1.N == 0) v = 10.0;
+        else {
+            v = 0.0;
+            #pragma unroll 1
+            for (int d1 = 1; d1 <= 6; d1++) {          // chance node, depth 4
+                const u32 e1 = pk_sel<S>(Tb, s1.posN, d1), pp1 = pk_pair(s1.posN, e1);
+                double worst = inf, beta = inf;        // min node, depth 3: (alpha from the root, beta = +inf)
+                #pragma unroll 1
+                for (int q = 0; q < 6; q++) {
+                    const int qs = q >= 3 ? 1 : 0, qd = q - 3 * qs;
+                    const int qc = (int)((qs ? e1 >> 8 : e1) & 7u), qb = (int)((qs ? pp1 >> 8 : pp1) & 0xFFu);
+                    const int dn = Tb->nbn[qd][qb];
+                    if (dn == 255) continue;
+                    RState<S> s2 = s1;
+                    rs_move<S, false>(s2, qc, dn);
+                    double val;
+                    if (dn == Tb->ri_origin || s2.P == 0) val = -10.0;
+                    else {
+                        val = 0.0;
+                        #pragma unroll 1
+                        for (int d2 = 1; d2 <= 6; d2++) {   // chance node, depth 2
+                            const u32 e2 = pk_sel<S>(Tb, s2.posP, d2), pp2 = pk_pair(s2.posP, e2);
+                            u32 bestr = 0;                   // max node, depth 1: rank 0 = -inf
+                            double a = alpha;
+                            #pragma unroll 1
+                            for (int m = 0; m < 6; m++) {
+                                const int ms = m >= 3 ? 1 : 0, md = m - 3 * ms;
+                                const int mb = (int)((ms ? pp2 >> 8 : pp2) & 0xFFu);
+                                const int dp = Tb->nbp[md][mb];
+                                if (dp == 255) continue;
+                                const M bd = one << dp;
+                                const M P3 = (s2.P & ~(one << (mb & 63))) | bd, N3 = s2.N & ~bd;
+                                u32 lr = Tb->rank[Tb->lutx[clz_m(P3)] + popc_m(P3) * IXN + Tb->luty[clz_m(N3)] + popc_m(N3)];
+                                if (dp == FastTab<S>::CELLS - 1 || N3 == 0) lr = rank10;   // evaluate() of a won position
+                                bestr = max(bestr, lr);
+                                a = fmax(a, Tb->val[bestr]);
+                                if (beta <= a) break;
+                            }
+                            val = val + Tb->val6[bestr];
+                        }
+                    }
+                    if (val < worst) worst = val;
+                    beta = fmin(beta, worst);
+                    if (beta <= alpha) break;
+                }
+                v = v + worst / 6.0;
+            }
+        }
+        if (v > best) { best = v; bflag = slot == 0 ? (int)(e0 >> 15) : 0; bdir = dir; }
+        alpha = fmax(alpha, best);
+    }
+    return best;
+}
+
 // Depth-3 hybrid search in ring space, shared by T lanes (sub = my index in the group).
 // Every lane of the group returns the same (value, action).
 template <int S, int T>
@@ -119,6 +198,8 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
     const bool have0 = !(rb0 & PK_OFF), have1 = !(rb1 & PK_OFF);
     const int flag0 = (int)(rsel >> 15);
     const int rp0 = rb0 & 63, rp1 = rb1 & 63;
+
+    if (depth >= 5) return d5_search<S>(Tb, c, dice, bflag, bdir); // every lane of the group on its own (dispatch uses T = 1)
 
     double best = -__builtin_inf(); // alpha = max(alpha, best_val): the running best (root beta stays +inf)
     bflag = 0; bdir = 0;
@@ -498,6 +579,7 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
         if ((int)threadIdx.x < nq) ((uint4 *)lds)[threadIdx.x] = st0;
         if ((int)threadIdx.x + D3_BS < nq) ((uint4 *)lds)[threadIdx.x + D3_BS] = st1;
     } else block_copy_in(lds, gsrc, nbytes);
+    lds_dma_wait(); // this wave's table chunks are in LDS before any other wave is let past the barrier (ewn_kernels.hip)
     __syncthreads();
     d3_decode<S, T>(live ? mine : lds, sub, garr + gl * 16, s); // every lane takes part (DPP combine); non-live lanes read game 0 of the block
     const bool active = live && !frozen;

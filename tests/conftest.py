@@ -28,3 +28,4 @@ def golden():
             cache[name] = load_golden(name)
         return cache[name]
     return get
+

@@ -51,8 +51,9 @@ def test_config_validation_on_host():
     assert lib.ewn_rng_words(None) == -2
     assert lib.ewn_step_scratch_bytes(C.byref(cfg())) == 0
     assert lib.ewn_step_scratch_bytes(C.byref(cfg(opponent_kind=2))) == 64 * (4 + 4 + 24 + 25)
-    # MT kind with auto-reset: phase word + 2 x per-block counts + 2 x per-block request regions (64 lanes = 1 block of 64 games)
-    assert lib.ewn_step_scratch_bytes(C.byref(cfg(autoreset=1))) == 16 + 2 * 4 * 4 + 2 * 1 * 128 * 16
+    # MT kind with auto-reset: phase word + 2 x per-block counts + 2 x per-block request regions, for the lanes-per-game choice
+    # that needs most (64 lanes, one lane per game: 1 block of 256 game slots, two requests each)
+    assert lib.ewn_step_scratch_bytes(C.byref(cfg(autoreset=1))) == 16 + 2 * 4 * 4 + 2 * 1 * 512 * 16
     assert lib.ewn_step_scratch_bytes(C.byref(cfg(autoreset=1, rng_kind=1))) == 0
 
 
@@ -81,3 +82,17 @@ def test_product_fails_loudly_without_gpu_or_library(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libewn_hip.so")
     with pytest.raises(ewn_gym_amd.EwnError):
         _lib.load()
+
+
+def test_mt_refill_queue_fits_every_lanes_per_game_choice():
+    """ewn_step_scratch_bytes for the MT19937 kind must cover the refill hand-off area for whichever lanes-per-game T the step
+    launch picks: ctrl 16 B | cnt [2][nb4] u32 | list [2][nblk][2 * 256 / T] x 16 B, nblk = ceil(N / (256 / T)).  (A 64-lane,
+    T = 1 launch once wrote 8 KB past a buffer sized for T = 4.)"""
+    lib = _lib.load()
+    for N in (1, 63, 64, 65, 255, 256, 257, 1000, 3000, 4096, 65536, 100001):
+        have = int(lib.ewn_step_scratch_bytes(C.byref(cfg(n_lanes=N, autoreset=1))))
+        for T in (1, 2, 4):
+            gpb = 256 // T
+            nblk = (N + gpb - 1) // gpb
+            nb4 = (nblk + 3) // 4 * 4
+            assert have >= 16 + 2 * nb4 * 4 + 2 * nblk * (2 * gpb) * 16, (N, T, have)
