@@ -594,3 +594,45 @@ def test_g13_cube_layers_4_and_5(ea, golden):
                 a0, a1, v = r["res"][key]
                 assert acts[i].tolist() == [a0, a1] and float(vals[i]).hex() == float.fromhex(v).hex(), (S, L, key, i)
         _run_group(ea, grp["traj"], "minimax", max_depth=2, heuristic="hybrid")
+
+
+def test_no_kernel_writes_outside_its_buffers(ea, monkeypatch):
+    """Every tensor VecEWN hands to the C ABI is carved out of a larger allocation with 4 KB of 0xA5 on either side; after stepping
+    (auto-reset, both RNG kinds, every opponent, every lanes-per-game choice of the lean kernel) the guards must be intact.
+    (Added after a refill queue sized for 4 lanes per game let a one-lane-per-game launch write 8 KB past it.)"""
+    from ewn_gym_amd import vec_env
+    G = 4096
+    guarded = []
+    real_zeros = torch.zeros
+
+    def guarded_zeros(shape, dtype=torch.float32, device=None):
+        if device is None or torch.device(device).type != "cuda":
+            return real_zeros(shape, dtype=dtype, device=device)
+        shape = (shape,) if isinstance(shape, int) else tuple(shape)
+        nbytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        pad = (nbytes + 511) // 512 * 512
+        buf = torch.full((G + pad + G,), 0xA5, dtype=torch.uint8, device=device)
+        buf[G:G + pad] = 0
+        guarded.append((buf, pad))
+        return buf[G:G + nbytes].view(dtype).view(shape)
+
+    cases = [dict(n=64, opponent_policy="minimax", max_depth=5, rng="mt19937"), dict(n=64, opponent_policy="random", rng="mt19937"),
+             dict(n=300, opponent_policy="minimax", max_depth=3, rng="mt19937"), dict(n=3000, opponent_policy="random", rng="mt19937"),
+             dict(n=257, opponent_policy="minimax", max_depth=3, rng="philox"), dict(n=40000, opponent_policy="minimax", max_depth=3, rng="mt19937"),
+             dict(n=100, opponent_policy="mcts", num_simulations=3, num_env_copies=2, rng="philox"),
+             dict(n=70, opponent_policy="minimax", max_depth=2, heuristic="attk", rng="mt19937", board_size=7, cube_layer=4)]
+    for kw in cases:
+        kw = dict(kw)
+        n = kw.pop("n")
+        monkeypatch.setattr(vec_env.torch, "zeros", guarded_zeros)
+        try:
+            env = ea.VecEWN(n, autoreset=True, want_terminal_obs=True, want_random_action=True, **kw)
+        finally:
+            monkeypatch.setattr(vec_env.torch, "zeros", real_zeros)
+        env.reset(seeds=np.arange(n) + 3)
+        for t in range(25):
+            env.step(env.sample_legal_actions(t))
+        torch.cuda.synchronize()
+        for buf, pad in guarded:
+            assert bool((buf[:G] == 0xA5).all()) and bool((buf[G + pad:] == 0xA5).all()), kw
+        guarded.clear()
