@@ -636,3 +636,21 @@ def test_no_kernel_writes_outside_its_buffers(ea, monkeypatch):
         for buf, pad in guarded:
             assert bool((buf[:G] == 0xA5).all()) and bool((buf[G + pad:] == 0xA5).all()), kw
         guarded.clear()
+    # the stateless queries allocate their outputs with torch.zeros too
+    for (S, L, M) in ((5, 3, 1), (5, 3, 63), (7, 3, 1000), (8, 5, 77), (6, 4, 130)):
+        b, d = _random_positions(S, L, M, 900 + M, max_steps=20)
+        d = np.minimum(d, 6).astype(np.int8)
+        monkeypatch.setattr(vec_env.torch, "zeros", guarded_zeros)
+        try:
+            ea.predict_minimax(b, d, 3, "hybrid", cube_layer=L)
+            ea.predict_minimax(b, d, 2, "attk", cube_layer=L)
+            ea.predict_mcts(b, d, num_simulations=7, num_env_copies=3, key=M, cube_layer=L)
+            ea.playout_wins(b, first_player=2, n_sims=37, key=M, cube_layer=L)
+            ea.evaluate(b, "hybrid", cube_layer=L)
+            ea.predict_random(b, d, key=M, step=3, cube_layer=L) if hasattr(ea, "predict_random") else None
+        finally:
+            monkeypatch.setattr(vec_env.torch, "zeros", real_zeros)
+        torch.cuda.synchronize()
+        for buf, pad in guarded:
+            assert bool((buf[:G] == 0xA5).all()) and bool((buf[G + pad:] == 0xA5).all()), (S, L, M)
+        guarded.clear()
