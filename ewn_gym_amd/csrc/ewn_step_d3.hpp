@@ -199,8 +199,6 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
     const int flag0 = (int)(rsel >> 15);
     const int rp0 = rb0 & 63, rp1 = rb1 & 63;
 
-    if (depth >= 5) return d5_search<S>(Tb, c, dice, bflag, bdir); // every lane of the group on its own (dispatch uses T = 1)
-
     double best = -__builtin_inf(); // alpha = max(alpha, best_val): the running best (root beta stays +inf)
     bflag = 0; bdir = 0;
 
@@ -387,6 +385,7 @@ __device__ __forceinline__ double fast_d3(const FastTab<S> *Tb, const GState<1> 
         s.posP |= (u64)(ap ? rp : PK_OFF) << (8 * k);
         s.posN |= (u64)(an ? rn : PK_OFF) << (8 * k);
     }
+    if (depth >= 5) return d5_search<S>(Tb, s, dice, bflag, bdir);
     return d3_search<S, 1>(Tb, s, dice, 0, depth, bflag, bdir);
 }
 
@@ -600,6 +599,7 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
     // so the DPP exchanges inside always see their partners
     int oflag = 0, odir = 0;
     if constexpr (OPP == 0) d3_search<S, T>(Tb, s, dice, sub, c.depth, oflag, odir);
+    if constexpr (OPP == 2) d5_search<S>(Tb, s, dice, oflag, odir); // max_depth 5 / 6: its own instance (T = 1), so its registers do not weigh on the others
     if (reply) {
         // opponent half, envs/ewn.py:464-486
         const u32 e = pk_sel<S>(Tb, s.posP, dice);
