@@ -108,7 +108,7 @@ typedef struct ewn_state {
     double *prev_score;  /* [N]  shaped env only (training_ewn.py:35), may be NULL otherwise */
     int32_t *tolerance;  /* [N]  shaped env only (training_ewn.py:38), may be NULL otherwise */
     const void *tables;  /* device copy of ewn_build_tables() output, or NULL.  When present and the config is
-                            (cube_layer 3, un-shaped; RandomAgent opponent, or minimax with max_depth 1..4 and
+                            (cube_layer 3, un-shaped; RandomAgent opponent, or minimax with max_depth 1..6 and
                             'hybrid') ewn_step runs the specialised table-driven kernel; results are identical
                             either way. */
 } ewn_state;
@@ -139,7 +139,7 @@ int ewn_rng_words(const ewn_config *cfg);
 int64_t ewn_step_scratch_bytes(const ewn_config *cfg);
 
 /* Search and move-selection tables of the specialised kernel (leaf-value ranks, ring-order geometry, dice -> cube
- * selectors; two images: max_depth <= 3 and max_depth 4, whose leaves are six-dice averages of evaluate();
+ * selectors; two images: max_depth 1-3 and 5, and max_depth 4 and 6, whose leaves are six-dice averages of evaluate();
  * ewn_gym_amd/csrc/ewn_fast.hpp).  Pure host computation: ewn_tables_bytes() gives the size
  * (0 = no specialised kernel for this geometry), ewn_build_tables() fills a HOST buffer the
  * caller then copies to the device and passes as ewn_state.tables / the `tables` argument. */
