@@ -1,0 +1,44 @@
+"""One-off soak: lock-step HIP vs CPU oracle on many lanes and steps (all six outputs bit-exact), beyond what tests/ runs.
+usage (GPU box): python tools/soak_parity.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import ewn_gym_amd as ea
+from oracle import pyoracle as po
+
+def bits(x): return np.asarray(x, np.float64).view(np.int64)
+def run(N, steps, lo, hi, **kw):
+    okw = dict(kw); opp = okw.pop("opponent_policy")
+    env = ea.VecEWN(N, opponent_policy=opp, autoreset=True, seed_stride=N, **okw)
+    seeds = (np.arange(N, dtype=np.uint64) * 11 + 17).astype(np.uint32)
+    env.reset(seeds=seeds)
+    orc = po.OracleVecEnv(hi - lo, opponent=opp, autoreset=True, seed_stride=N, lane_offset=lo, **okw)
+    orc.reset(seeds=seeds[lo:hi])
+    gen = np.random.Generator(np.random.PCG64(N))
+    t0 = time.time(); nterm = 0
+    for t in range(steps):
+        a = env.sample_legal_actions(t).clone()
+        if t % 4 == 3:   # raw actions, illegal ones included
+            raw = torch.from_numpy(np.stack([gen.integers(0, 2, N), gen.integers(0, 3, N)], 1).astype(np.int8)).cuda()
+            a.copy_(raw)
+        oa = a[lo:hi].cpu().numpy()
+        res = env.step(a)
+        ores = orc.step(oa)
+        for k in range(6):
+            x, o = res[k][lo:hi].cpu().numpy(), ores[k]
+            assert np.array_equal(bits(x) if k == 2 else x, bits(o) if k == 2 else o), (kw, t, k)
+        nterm += int(ores[3].sum())
+    print("ok N=%d steps=%d slice=%d episodes=%d %r (%.1f s)" % (N, steps, hi - lo, nterm, kw, time.time() - t0), flush=True)
+
+run(40000, 120, 1000, 3000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=5)
+run(40000, 120, 35000, 37000, opponent_policy="minimax", max_depth=3, rng="mt19937")
+run(300000, 40, 299000, 300000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=6)
+run(9000, 80, 0, 3000, opponent_policy="minimax", max_depth=4, rng="philox", philox_key=7)
+run(5000, 60, 100, 1100, opponent_policy="minimax", max_depth=1, rng="mt19937")
+run(5000, 60, 100, 1100, opponent_policy="minimax", max_depth=2, rng="philox", philox_key=8)
+run(3000, 25, 0, 600, opponent_policy="minimax", max_depth=5, rng="philox", philox_key=9)
+run(60000, 150, 20000, 24000, opponent_policy="random", rng="mt19937")
+run(60000, 150, 20000, 24000, opponent_policy="random", rng="philox", philox_key=10)
+run(20000, 60, 5000, 6000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=11, board_size=7)
+run(20000, 40, 5000, 5600, opponent_policy="minimax", max_depth=4, rng="mt19937", board_size=8)
+print("soak passed")
