@@ -30,15 +30,43 @@ def run(N, steps, lo, hi, **kw):
         nterm += int(ores[3].sum())
     print("ok N=%d steps=%d slice=%d episodes=%d %r (%.1f s)" % (N, steps, hi - lo, nterm, kw, time.time() - t0), flush=True)
 
-run(40000, 120, 1000, 3000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=5)
-run(40000, 120, 35000, 37000, opponent_policy="minimax", max_depth=3, rng="mt19937")
-run(300000, 40, 299000, 300000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=6)
-run(9000, 80, 0, 3000, opponent_policy="minimax", max_depth=4, rng="philox", philox_key=7)
-run(5000, 60, 100, 1100, opponent_policy="minimax", max_depth=1, rng="mt19937")
-run(5000, 60, 100, 1100, opponent_policy="minimax", max_depth=2, rng="philox", philox_key=8)
-run(3000, 25, 0, 600, opponent_policy="minimax", max_depth=5, rng="philox", philox_key=9)
-run(60000, 150, 20000, 24000, opponent_policy="random", rng="mt19937")
-run(60000, 150, 20000, 24000, opponent_policy="random", rng="philox", philox_key=10)
-run(20000, 60, 5000, 6000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=11, board_size=7)
-run(20000, 40, 5000, 5600, opponent_policy="minimax", max_depth=4, rng="mt19937", board_size=8)
-print("soak passed")
+if len(sys.argv) > 1 and sys.argv[1] == "mcts":
+    pass
+else:
+  run(40000, 120, 1000, 3000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=5)
+  run(40000, 120, 35000, 37000, opponent_policy="minimax", max_depth=3, rng="mt19937")
+  run(300000, 40, 299000, 300000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=6)
+  run(9000, 80, 0, 3000, opponent_policy="minimax", max_depth=4, rng="philox", philox_key=7)
+  run(5000, 60, 100, 1100, opponent_policy="minimax", max_depth=1, rng="mt19937")
+  run(5000, 60, 100, 1100, opponent_policy="minimax", max_depth=2, rng="philox", philox_key=8)
+  run(3000, 25, 0, 600, opponent_policy="minimax", max_depth=5, rng="philox", philox_key=9)
+  run(60000, 150, 20000, 24000, opponent_policy="random", rng="mt19937")
+  run(60000, 150, 20000, 24000, opponent_policy="random", rng="philox", philox_key=10)
+  run(20000, 60, 5000, 6000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=11, board_size=7)
+  run(20000, 40, 5000, 5600, opponent_policy="minimax", max_depth=4, rng="mt19937", board_size=8)
+  print("soak passed")
+
+# flat Monte-Carlo: every win count must match the oracle (shared playout generator)
+def positions(S, L, n, seed, max_steps=24):
+    orc = po.OracleVecEnv(n, board_size=S, cube_layer=L, rng="philox", philox_key=seed, autoreset=True)
+    orc.reset(seeds=np.arange(n) + seed)
+    gen = np.random.Generator(np.random.PCG64(seed))
+    when = gen.integers(0, max_steps, n)
+    out, _ = orc.obs(); out = out.copy()
+    for t in range(max_steps):
+        b = orc.step(orc.sample_legal_actions(t))[0]
+        out[when == t] = b[when == t]
+    return out, gen.integers(1, 7, n).astype(np.int8)
+
+if len(sys.argv) > 1 and sys.argv[1] == "mcts":
+    for S, n, total in ((5, 300, 1000), (7, 120, 400), (8, 60, 333), (5, 2000, 13)):
+        b, d = positions(S, 3, n, 77 + S)
+        t0 = time.time()
+        acts, wins = ea.predict_mcts(b, d, num_simulations=total, num_env_copies=1, key=S * 7 + total)
+        oa, ow = po.predict_mcts(b, d, num_simulations=total, num_env_copies=1, key=S * 7 + total)
+        assert np.array_equal(wins.cpu().numpy(), ow) and np.array_equal(acts.cpu().numpy(), oa), (S, n, total)
+        w = po.playout_wins(b, 2, total, key=5)
+        assert np.array_equal(ea.playout_wins(b, first_player=2, n_sims=total, key=5).cpu().numpy(), w)
+        print("ok mcts S=%d positions=%d playouts/root=%d (%.1f s)" % (S, n, total, time.time() - t0), flush=True)
+    run(3000, 30, 0, 3000, opponent_policy="mcts", num_simulations=4, num_env_copies=3, rng="philox", philox_key=3)
+    print("mcts soak passed")
