@@ -150,21 +150,40 @@ __device__ __forceinline__ double d5_search(const FastTab<S> *Tb, const RState<S
                         #pragma unroll 1
                         for (int d2 = 1; d2 <= 6; d2++) {   // chance node, depth 2
                             const u32 e2 = pk_sel<S>(Tb, s2.posP, d2), pp2 = pk_pair(s2.posP, e2);
-                            u32 bestr = 0;                   // max node, depth 1: rank 0 = -inf
-                            double a = alpha;
-                            #pragma unroll 1
+                            // max node, depth 1.  All (at most six) leaves first, their LDS reads batched in three stages, then the
+                            // reference's loop in registers: a move that does not exist is skipped; after each real move
+                            // best = max(best, leaf), alpha' = max(alpha, best), stop once beta <= alpha'.
+                            u32 lx[6], ly[6], lr[6];
+                            bool ex[6], won[6];
+                            #pragma unroll
                             for (int m = 0; m < 6; m++) {
                                 const int ms = m >= 3 ? 1 : 0, md = m - 3 * ms;
                                 const int mb = (int)((ms ? pp2 >> 8 : pp2) & 0xFFu);
                                 const int dp = Tb->nbp[md][mb];
-                                if (dp == 255) continue;
-                                const M bd = one << dp;
+                                ex[m] = dp != 255;
+                                const M bd = ex[m] ? (one << (dp & 63)) : (M)0;
                                 const M P3 = (s2.P & ~(one << (mb & 63))) | bd, N3 = s2.N & ~bd;
-                                u32 lr = Tb->rank[Tb->lutx[clz_m(P3)] + popc_m(P3) * IXN + Tb->luty[clz_m(N3)] + popc_m(N3)];
-                                if (dp == FastTab<S>::CELLS - 1 || N3 == 0) lr = rank10;   // evaluate() of a won position
-                                bestr = max(bestr, lr);
-                                a = fmax(a, Tb->val[bestr]);
-                                if (beta <= a) break;
+                                won[m] = dp == FastTab<S>::CELLS - 1 || N3 == 0;          // evaluate() of a won position: +10
+                                lx[m] = Tb->lutx[clz_m(P3)] + popc_m(P3) * IXN;
+                                ly[m] = Tb->luty[clz_m(N3)] + popc_m(N3);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            #pragma unroll
+                            for (int m = 0; m < 6; m++) lr[m] = Tb->rank[lx[m] + ly[m]];
+                            __builtin_amdgcn_sched_barrier(0);
+                            double lv[6];
+                            #pragma unroll
+                            for (int m = 0; m < 6; m++) { lr[m] = won[m] ? rank10 : lr[m]; lv[m] = Tb->val[lr[m]]; }
+                            __builtin_amdgcn_sched_barrier(0);
+                            u32 bestr = 0;                   // rank 0 = -inf
+                            double bestv = -inf;
+                            bool stop = false;
+                            #pragma unroll
+                            for (int m = 0; m < 6; m++) {
+                                const bool live = ex[m] && !stop;
+                                bestr = live ? max(bestr, lr[m]) : bestr;
+                                bestv = live ? fmax(bestv, lv[m]) : bestv;
+                                stop = stop || (live && beta <= fmax(alpha, bestv));
                             }
                             val = val + Tb->val6[bestr];
                         }

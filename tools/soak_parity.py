@@ -39,7 +39,9 @@ else:
   run(9000, 80, 0, 3000, opponent_policy="minimax", max_depth=4, rng="philox", philox_key=7)
   run(5000, 60, 100, 1100, opponent_policy="minimax", max_depth=1, rng="mt19937")
   run(5000, 60, 100, 1100, opponent_policy="minimax", max_depth=2, rng="philox", philox_key=8)
-  run(3000, 25, 0, 600, opponent_policy="minimax", max_depth=5, rng="philox", philox_key=9)
+  run(3000, 25, 0, 800, opponent_policy="minimax", max_depth=5, rng="philox", philox_key=9)
+  run(1500, 20, 0, 300, opponent_policy="minimax", max_depth=6, rng="mt19937")
+  run(2000, 20, 0, 300, opponent_policy="minimax", max_depth=5, rng="philox", philox_key=12, board_size=7)
   run(60000, 150, 20000, 24000, opponent_policy="random", rng="mt19937")
   run(60000, 150, 20000, 24000, opponent_policy="random", rng="philox", philox_key=10)
   run(20000, 60, 5000, 6000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=11, board_size=7)
