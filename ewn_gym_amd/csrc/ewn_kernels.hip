@@ -953,7 +953,8 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
         if (fast && (cfg->max_depth == 4 || cfg->max_depth == 6)) ks.tables = (const int8_t *)st->tables + fast_tables_bytes(g.S, g.L); // the max_depth-4 image
         if ((fast || lean_random) && !cfg->shaped && d3_threads_per_game(k.N) > 0) {
             // the lean fused kernel: canonical ring space end to end, T lanes per game (ewn_step_d3.hpp)
-            const int T = (lean_random || cfg->max_depth < 3 || cfg->max_depth > 4) ? 1 : d3_threads_per_game(k.N); // leaves are shared at depth 3-4 only
+            // leaves are shared among lanes at depth 3-4; depth 5-6 splits its inner dice over two lanes while the chip is not full
+            const int T = (lean_random || cfg->max_depth < 3) ? 1 : (cfg->max_depth > 4 ? (k.N <= 131072 && d3_threads_per_game(k.N) != 1 ? 2 : 1) : d3_threads_per_game(k.N));
             const int gpb0 = D3_BS / T, step_blocks = (k.N + gpb0 - 1) / gpb0;
             // MT kind with auto-reset: window refills are extra blocks of the same launch (needs the caller's scratch)
             const bool fused_refill = refill && scratch != nullptr;
@@ -975,7 +976,7 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
 #define D3_LDS(SS) (l3 + FAST_TAB_BYTES(SS) > need_refill ? l3 + FAST_TAB_BYTES(SS) : need_refill)
 #define D3_LAUNCH(SS, TT, OO) do { if (k.rng_kind == 0) k_step_d3<SS, TT, OO, 0><<<grid, D3_BS, D3_LDS(SS), s>>>(dc, db); \
                                    else k_step_d3<SS, TT, OO, 1><<<grid, D3_BS, D3_LDS(SS), s>>>(dc, db); } while (0)
-#define D3_BY_T(SS) do { if (lean_random) D3_LAUNCH(SS, 1, 1); else if (cfg->max_depth > 4) D3_LAUNCH(SS, 1, 2); else if (T == 1) D3_LAUNCH(SS, 1, 0); else if (T == 2) D3_LAUNCH(SS, 2, 0); else D3_LAUNCH(SS, 4, 0); } while (0)
+#define D3_BY_T(SS) do { if (lean_random) D3_LAUNCH(SS, 1, 1); else if (cfg->max_depth > 4) { if (T == 2) D3_LAUNCH(SS, 2, 2); else D3_LAUNCH(SS, 1, 2); } else if (T == 1) D3_LAUNCH(SS, 1, 0); else if (T == 2) D3_LAUNCH(SS, 2, 0); else D3_LAUNCH(SS, 4, 0); } while (0)
             switch (g.S) {
             case 5: D3_BY_T(5); break;
             case 6: D3_BY_T(6); break;

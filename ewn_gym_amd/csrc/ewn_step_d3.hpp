@@ -108,9 +108,10 @@ EWN_DEV void rs_move(RState<S> &s, int k, int q)
 // byte-per-cube state and the table leaf.  One lane per game; breaks diverge between the lanes of a wave, trip counts are
 // bounded (6^5 leaves).  A leaf is a rank lookup, an inner node a masked move: ~20x fewer instructions than the generic
 // template recursion on GState.
-template <int S>
-__device__ __forceinline__ double d5_search(const FastTab<S> *Tb, const RState<S> &c, int dice, int &bflag, int &bdir)
+template <int S, int T = 1>
+__device__ __forceinline__ double d5_search(const FastTab<S> *Tb, const RState<S> &c, int dice, int sub, int &bflag, int &bdir)
 {
+    static_assert(T == 1 || T == 2, "the six dice of the inner chance node are split over one or two lanes");
     typedef typename MaskOf<S>::type M;
     constexpr int IXN = FastTab<S>::IXN;
     const M one = 1;
@@ -147,8 +148,10 @@ __device__ __forceinline__ double d5_search(const FastTab<S> *Tb, const RState<S
                     if (dn == Tb->ri_origin || s2.P == 0) val = -10.0;
                     else {
                         val = 0.0;
-                        #pragma unroll 1
-                        for (int d2 = 1; d2 <= 6; d2++) {   // chance node, depth 2
+                        u32 br[6 / T];                       // my dice: d2 = sub + 1, sub + 1 + T, ...
+                        #pragma unroll
+                        for (int j = 0; j < 6 / T; j++) {   // chance node, depth 2 (the T lanes of the game share its six dice)
+                            const int d2 = sub + 1 + T * j;
                             const u32 e2 = pk_sel<S>(Tb, s2.posP, d2), pp2 = pk_pair(s2.posP, e2);
                             // max node, depth 1.  All (at most six) leaves first, their LDS reads batched in three stages, then the
                             // reference's loop in registers: a move that does not exist is skipped; after each real move
@@ -185,8 +188,19 @@ __device__ __forceinline__ double d5_search(const FastTab<S> *Tb, const RState<S
                                 bestv = live ? fmax(bestv, lv[m]) : bestv;
                                 stop = stop || (live && beta <= fmax(alpha, bestv));
                             }
-                            val = val + Tb->val6[bestr];
+                            br[j] = bestr;
                         }
+                        u32 bd6[6];
+                        #pragma unroll
+                        for (int j = 0; j < 6 / T; j++) {
+                            if constexpr (T == 1) bd6[j] = br[j];
+                            else { bd6[2 * j] = dpp_u32<Bcast<2, 0>::CTRL>(br[j]); bd6[2 * j + 1] = dpp_u32<Bcast<2, 1>::CTRL>(br[j]); }
+                        }
+                        double q6[6];
+                        #pragma unroll
+                        for (int d = 0; d < 6; d++) q6[d] = Tb->val6[bd6[d]];
+                        #pragma unroll
+                        for (int d = 0; d < 6; d++) val = val + q6[d];   // expected_val += val / 6 in dice order
                     }
                     if (val < worst) worst = val;
                     beta = fmin(beta, worst);
@@ -404,7 +418,7 @@ __device__ __forceinline__ double fast_d3(const FastTab<S> *Tb, const GState<1> 
         s.posP |= (u64)(ap ? rp : PK_OFF) << (8 * k);
         s.posN |= (u64)(an ? rn : PK_OFF) << (8 * k);
     }
-    if (depth >= 5) return d5_search<S>(Tb, s, dice, bflag, bdir);
+    if (depth >= 5) return d5_search<S, 1>(Tb, s, dice, 0, bflag, bdir);
     return d3_search<S, 1>(Tb, s, dice, 0, depth, bflag, bdir);
 }
 
@@ -618,7 +632,7 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
     // so the DPP exchanges inside always see their partners
     int oflag = 0, odir = 0;
     if constexpr (OPP == 0) d3_search<S, T>(Tb, s, dice, sub, c.depth, oflag, odir);
-    if constexpr (OPP == 2) d5_search<S>(Tb, s, dice, oflag, odir); // max_depth 5 / 6: its own instance (T = 1), so its registers do not weigh on the others
+    if constexpr (OPP == 2) d5_search<S, (T > 2 ? 2 : T)>(Tb, s, dice, sub, oflag, odir); // max_depth 5 / 6: its own instances (T = 1, 2), so its registers do not weigh on the others
     if (reply) {
         // opponent half, envs/ewn.py:464-486
         const u32 e = pk_sel<S>(Tb, s.posP, dice);
