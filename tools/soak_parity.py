@@ -72,3 +72,15 @@ if len(sys.argv) > 1 and sys.argv[1] == "mcts":
         print("ok mcts S=%d positions=%d playouts/root=%d (%.1f s)" % (S, n, total, time.time() - t0), flush=True)
     run(3000, 30, 0, 3000, opponent_policy="mcts", num_simulations=4, num_env_copies=3, rng="philox", philox_key=3)
     print("mcts soak passed")
+
+if len(sys.argv) > 1 and sys.argv[1] == "predict":
+    # stateless ExpectiMinimaxAgent.predict, table-driven path against the oracle: action and root value bit patterns
+    for S in (5, 6, 7, 8):
+        for depth, n in ((1, 20000), (2, 20000), (3, 30000), (4, 20000), (5, 3000), (6, 600)):
+            b, d = positions(S, 3, n, 4000 + 10 * S + depth, max_steps=14 if S == 5 else 26)
+            t0 = time.time()
+            acts, vals = ea.predict_minimax(b, d, depth, "hybrid")
+            oa, ov, _ = po.predict_minimax(b, d, depth, "hybrid")
+            assert np.array_equal(acts.cpu().numpy(), oa) and np.array_equal(bits(vals.cpu().numpy()), bits(ov)), (S, depth)
+            print("ok predict S=%d depth=%d positions=%d (%.1f s)" % (S, depth, n, time.time() - t0), flush=True)
+    print("predict soak passed")
