@@ -763,11 +763,11 @@ static int d3_threads_per_game(int n_games)
 {
     static const int forced = [] { const char *e = getenv("EWN_D3_T"); return e ? atoi(e) : -1; }();
     if (forced == 0 || forced == 1 || forced == 2 || forced == 4) return forced;
-    // measured on MI355X (tools/sweep_T.sh, us per step, T = 1 / 2 / 4): 16 384 games 18.1 / 12.2 / 10.8; 32 768: 18.4 / 12.6 / 13.3;
-    // 65 536: 18.9 / 16.1 / 19.6; 131 072: 25.1 / 24.1 / 32.6; 262 144: 42.0 / 42.6 / 57.9; 1 048 576: 139.8 / 143.7 / 202.9.
+    // measured on MI355X (tools/sweep_T.sh, us per step, T = 1 / 2 / 4): 16 384 games 14.9 / 10.9 / 10.0; 32 768: 15.1 / 11.3 / 12.6;
+    // 65 536: 15.8 / 14.8 / 18.7; 131 072: 21.6 / 22.4 / 32.3; 262 144: 36.3 / 39.4 / 57.5; 1 048 576: 118 / 132 / 205.
     // The kernel is bound by integer VALU issue once the chip is full, so lanes added beyond what hides the LDS/global
     // latency only add redundant instructions.
-    if (n_games >= 262144) return 1;
+    if (n_games >= 131072) return 1;
     if (n_games >= 32768) return 2;
     return 4;
 }

@@ -495,9 +495,9 @@ def test_full_size_properties_and_sharding(ea):
 
 
 def test_one_and_two_lanes_per_game_variants_at_large_lane_counts(ea):
-    """>= 262 144 lanes select the T = 1 instance of the lean step kernel (one lane per game), 32 768..131 072 the T = 2 one; a
+    """>= 131 072 lanes select the T = 1 instance of the lean step kernel (one lane per game), 32 768..131 071 the T = 2 one; a
     slice against the oracle, 7x7 included (64-bit occupancy masks)."""
-    for S, N, T in ((5, 262144, 8), (7, 131072, 6), (7, 262144, 4)):
+    for S, N, T in ((5, 262144, 8), (7, 100000, 6), (7, 131072, 4)):
         kw = dict(board_size=S, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=77, autoreset=True, seed_stride=N)
         seeds = (np.arange(N, dtype=np.uint64) * 3 + 5).astype(np.uint32)
         env = ea.VecEWN(N, **kw)
