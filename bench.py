@@ -1,18 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- env steps/sec of the vectorised EWN step + depth-3 expectiminimax opponent.
 
-One "step" = one pass of the hot path over one batch: a device-side stand-in agent
-plays a uniformly random LEGAL action per lane (RandomAgent; by default emitted by the step
-kernel itself for the new observation, or by a separate policy kernel with
---separate-agent-kernel), and ewn_step applies it, rolls the opponent's dice, runs the
-opponent's search/reply, tests for the win, rolls the next dice and auto-resets finished
-lanes -- for every lane.
+One "step" = one pass of the hot path over one batch: for every lane a device-side stand-in agent (RandomAgent:
+a uniformly random LEGAL action) moves, the engine rolls the opponent's dice, runs the opponent's search / reply,
+tests for the win, rolls the next dice and auto-resets finished lanes.
+
+Launch modes (`config.launch` says which one was timed):
+  rollout  (default)  ewn_step_k: K env steps per kernel launch, the game state stays in registers between the steps of a
+                      launch and EVERY step's observation, action, reward and flags are written to a [K][N] trajectory
+                      buffer in HBM (what a trainer's rollout buffer or an evaluation loop consumes);
+  step                one ewn_step launch per env step (what `env.step()` of one vector env is), the agent's next action
+                      emitted by the step kernel (ewn_step_out.random_action) -- round 1's headline, still reported in
+                      the extra field `single_step_launch`.
+Either way the timed region is hipGraph replays only, bracketed by barrier + synchronize and by one HIP event pair on the
+launch stream (`roofline.kernel_ms` = event time / launches, so it can never exceed the wall-clock figure).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--lanes 65536] [--opponent minimax] ...
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-
-Rank 0 prints ONE JSON line.  Inputs (boards, dice, RNG state) are resident in HBM
-before the timed region; no host<->device traffic happens inside it.
+`--gpus N` (N > 1) outside torchrun starts the N ranks itself (torch.distributed.run, one process per GPU, RCCL).
+Rank 0 prints ONE JSON line.  Inputs (boards, dice, RNG state) are resident in HBM before the timed region; no
+host<->device traffic happens inside it.
 """
 import argparse
 import json
@@ -37,22 +43,29 @@ def parse():
     ap.add_argument("--cube-layer", type=int, default=3)
     ap.add_argument("--opponent", default="minimax", choices=["random", "minimax", "mcts"])
     ap.add_argument("--max-depth", type=int, default=3)
+    ap.add_argument("--heuristic", default="hybrid")
     ap.add_argument("--rng", default="philox", choices=["philox", "mt19937"])
     ap.add_argument("--num-simulations", type=int, default=10, help="MctsAgent.num_simulations")
     ap.add_argument("--num-env-copies", type=int, default=5, help="MctsAgent.num_env_copies")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the N>1 path on one GPU)")
+    ap.add_argument("--mode", default="auto", choices=["auto", "rollout", "step"],
+                    help="rollout: ewn_step_k, --steps-per-launch env steps per kernel launch; step: one ewn_step launch per env step; "
+                         "auto: rollout where the engine has it for the configuration, else step")
+    ap.add_argument("--steps-per-launch", type=int, default=25, help="rollout mode: env steps per ewn_step_k launch")
+    ap.add_argument("--no-trajectory", action="store_true",
+                    help="rollout mode: do not write the per-step trajectory (only final state and per-lane counters)")
+    ap.add_argument("--agent", default="legal", choices=["legal", "uniform6"],
+                    help="stand-in agent: uniformly random LEGAL action (RandomAgent), or uniform over all 6 [flag, dir] actions "
+                         "(what an untrained A2C policy plays: illegal-move terminations; step mode only)")
     ap.add_argument("--separate-agent-kernel", action="store_true",
-                    help="sample the agent's action with a separate policy kernel (ewn_predict_random) instead of ewn_step's fused "
-                         "random_action output")
-    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly from Python instead of replaying a hipGraph")
-    ap.add_argument("--graph-steps", type=int, default=50, help="steps captured per graph")
+                    help="step mode: sample the agent's action with a separate policy kernel (ewn_predict_random) instead of "
+                         "ewn_step's fused random_action output")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly from Python instead of replaying a hipGraph")
+    ap.add_argument("--graph-steps", type=int, default=50, help="env steps captured per graph (step mode)")
     ap.add_argument("--mt-window", type=int, default=0, help="MT19937-compat mode: precomputed outputs per episode window (0 = engine default)")
-    ap.add_argument("--pipeline-groups", type=int, default=2,
-                    help="also report (extra field, not `value`) the rate of the same lanes split into this many groups that step on "
-                         "their own streams without a barrier between them; 0 = skip")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra measurements (single-step launch, no-trajectory rollout, uniform6 agent)")
     return ap.parse_args()
 
 
@@ -94,8 +107,148 @@ def cpu_baseline(args, budget_s):
             "sample": "%d processes x 2048 lanes, %.1f s wall (%d lane-steps) of the same workload on the CPU oracle" % (cores, dt, total)}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: become the launcher.  Nothing has touched the GPU yet (torch is
+    not even imported), so starting the N ranks as a child process and handing back its exit code is safe on this pool."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def source_hash():
+    """sha256 over the kernel sources: the PMC summary under profiles/ carries it, so a stale counter file is detected"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ewn_gym_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_key(mode, opponent, max_depth, rng, board_size, lanes, steps_per_launch, trajectory):
+    key = "%s_%s_d%d_%s_%dx%d_%d" % (mode, opponent, max_depth, rng, board_size, board_size, lanes)
+    if mode == "rollout":
+        key += "_k%d%s" % (steps_per_launch, "" if trajectory else "_notraj")
+    return key
+
+
+class Runner:
+    """One way of advancing `env` by env steps, captured into hipGraphs so that the timed region contains nothing but replays."""
+
+    def __init__(self, torch, env, args, mode, trajectory=True, agent="legal"):
+        self.torch, self.env, self.args, self.mode, self.agent = torch, env, args, mode, agent
+        self.N = env.N
+        self.counter = torch.zeros((), dtype=torch.int32, device="cuda")
+        self.fused_agent = mode == "step" and agent == "legal" and not args.separate_agent_kernel
+        self.kernels_per_step = 1.0
+        self.trajectory = trajectory
+        if mode == "rollout":
+            self.K = max(1, min(args.steps_per_launch, args.steps))
+            self.traj = env.alloc_rollout(self.K) if trajectory else None
+            self.kernels_per_step = 1.0 / self.K
+        else:
+            self.K = 1
+            if self.fused_agent:
+                # the stand-in agent is RandomAgent: ewn_step itself emits RandomAgent.predict(new observation) into
+                # ewn_step_out.random_action, and that buffer is the next step's `actions` (one kernel per step)
+                self.actions = env.random_action
+                env.sample_legal_actions(0, out=self.actions)
+            else:
+                self.actions = torch.zeros((self.N, 2), dtype=torch.int8, device="cuda")
+                self.kernels_per_step = 2.0
+            if agent == "uniform6":
+                self.gen = torch.Generator(device="cuda")
+                self.gen.manual_seed(2024 + env.cfg.lane_offset)
+                self.scale = torch.tensor([2.0, 3.0], device="cuda")
+        self.graphs = {}
+
+    def launch(self, n_steps):
+        """enqueue n_steps env steps"""
+        env, torch = self.env, self.torch
+        if self.mode == "rollout":
+            done = 0
+            while done < n_steps:
+                k = min(self.K, n_steps - done)
+                env.rollout(k, agent="random", traj=self.traj)
+                done += k
+            return
+        for _ in range(n_steps):
+            if self.agent == "uniform6":
+                # uniform over MultiDiscrete([2, 3]): what an untrained policy plays (illegal moves included)
+                u = torch.rand((self.N, 2), device="cuda", generator=self.gen)
+                self.actions.copy_((u * self.scale).to(torch.int8))
+            elif not self.fused_agent:
+                env.sample_legal_actions(0, out=self.actions, step_tensor=self.counter)   # RandomAgent as a separate policy kernel
+            env.step(self.actions)                                                        # the hot path
+            if not self.fused_agent and self.agent == "legal":
+                self.counter.add_(1)
+
+    def plan(self, steps):
+        """[(steps per graph, replays)] covering exactly `steps` env steps"""
+        g = max(1, min(self.args.graph_steps, steps))
+        if self.mode == "rollout":
+            g = min(steps, max(self.K, g // self.K * self.K))
+        out = [(g, steps // g)]
+        if steps % g:
+            out.append((steps % g, 1))
+        return out
+
+    def graph(self, n_steps):
+        torch = self.torch
+        if n_steps not in self.graphs:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            if self.agent == "uniform6" and self.mode == "step":
+                g.register_generator_state(self.gen)
+            with torch.cuda.graph(g):
+                self.launch(n_steps)
+            self.graphs[n_steps] = g
+        return self.graphs[n_steps]
+
+    def launches(self, steps):
+        """kernel launches of the dominant kernel the plan issues"""
+        if self.mode != "rollout":
+            return steps
+        n = 0
+        for g, reps in self.plan(steps):
+            n += reps * ((g + self.K - 1) // self.K)
+        return n
+
+    def run(self, steps, barrier, use_graph=True):
+        """time exactly `steps` env steps; returns (wall seconds, event milliseconds)"""
+        torch = self.torch
+        plan = self.plan(steps)
+        if use_graph:
+            for g, _ in plan:
+                self.graph(g)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        t0 = time.perf_counter()
+        e0.record()
+        for g, reps in plan:
+            for _ in range(reps):
+                if use_graph:
+                    self.graphs[g].replay()
+                else:
+                    self.launch(g)
+        e1.record()
+        barrier()
+        dt = time.perf_counter() - t0
+        return dt, e0.elapsed_time(e1)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,154 +269,111 @@ def main():
             dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(0)
-    if args.gpus != world:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if args.gpus != world and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     import ewn_gym_amd as ea
-    from ewn_gym_amd.sharding import lane_range
+    from ewn_gym_amd.sharding import lane_range, lane_seeds
 
     N = args.lanes
     lo, hi = lane_range(N * world, world, rank)  # weak scaling: every GPU owns N lanes, global ids [rank*N, (rank+1)*N)
-    env = ea.VecEWN(N, board_size=args.board_size, cube_layer=args.cube_layer, opponent_policy=args.opponent,
-                    max_depth=args.max_depth, rng=args.rng, autoreset=True, lane_offset=lo, seed_stride=N * world,
-                    philox_key=2024, num_simulations=args.num_simulations, num_env_copies=args.num_env_copies,
-                    want_random_action=not args.separate_agent_kernel, mt_window=args.mt_window)
-    from ewn_gym_amd.sharding import lane_seeds
-    env.reset(seeds=lane_seeds(lo, hi).cuda())  # reference default seed 9487 + global lane id
-    counter = torch.zeros((), dtype=torch.int32, device="cuda")  # device-side step index: lets the captured graph advance
-    fused_agent = not args.separate_agent_kernel
-    if fused_agent:
-        # The stand-in agent is RandomAgent: ewn_step itself emits RandomAgent.predict(new observation) into
-        # ewn_step_out.random_action, and that buffer is the next step's `actions` (one kernel per step).
-        actions = env.random_action
-        env.sample_legal_actions(0, out=actions)      # the very first action
-    else:
-        actions = torch.zeros((N, 2), dtype=torch.int8, device="cuda")
 
-    def one_step():
-        if not fused_agent:
-            env.sample_legal_actions(0, out=actions, step_tensor=counter)   # RandomAgent as a separate device policy kernel
-        env.step(actions)                                                   # the hot path
-        if not fused_agent:
-            counter.add_(1)
+    def make_env():
+        env = ea.VecEWN(N, board_size=args.board_size, cube_layer=args.cube_layer, opponent_policy=args.opponent,
+                        max_depth=args.max_depth, heuristic=args.heuristic, rng=args.rng, autoreset=True, lane_offset=lo,
+                        seed_stride=N * world, philox_key=2024, num_simulations=args.num_simulations,
+                        num_env_copies=args.num_env_copies, want_random_action=True, mt_window=args.mt_window)
+        env.reset(seeds=lane_seeds(lo, hi).cuda())  # reference default seed 9487 + global lane id
+        return env
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
-    # The per-step launch sequence is captured once in a hipGraph (same kernels, same order, same stream semantics) so the
-    # timed region measures the GPU, not Python's ctypes launch overhead (~7 us/step on this host).
-    graph = None
-    if not args.no_graph:
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            for _ in range(args.graph_steps):
-                one_step()
-    n_rep = args.steps // args.graph_steps if graph is not None else 0
-    n_tail = args.steps - n_rep * (args.graph_steps if graph is not None else 0)
-
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(n_rep):
-        graph.replay()
-    for _ in range(n_tail):
-        one_step()
-    barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+    env = make_env()
+    mode = args.mode
+    if mode == "auto":
+        mode = "rollout" if (args.agent == "legal" and not args.separate_agent_kernel and env.supports_rollout()) else "step"
+    runner = Runner(torch, env, args, mode, trajectory=not args.no_trajectory, agent=args.agent)
+    runner.launch(args.warmup)                                   # W untimed warm-up steps
+    dt, ev_ms = runner.run(args.steps, barrier, use_graph=not args.no_graph)   # exactly K timed steps
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if (world > 1 and args.backend == "nccl") else "cpu")
+    ranks_seen = None
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        one = torch.ones(1, dtype=torch.int32, device=tmax.device)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)               # every rank of the process group took part
+        ranks_seen = int(one.item())
     dt = float(tmax.item())
+    # a digest of the final state: the same lanes give the same digest however they are sharded (tests compare it)
+    digest = int((env.board.to(torch.int64).reshape(N, -1) * torch.arange(1, args.board_size ** 2 + 1, device="cuda")).sum().item())
+    if world > 1:
+        dg = torch.tensor([digest], dtype=torch.int64, device=tmax.device)
+        dist.all_reduce(dg, op=dist.ReduceOp.SUM)
+        digest = int(dg.item())
 
-    # Extra, clearly labelled: the same lanes as H independent groups, each stepping on its own stream inside one hipGraph.  With
-    # the fused RandomAgent a group's step k+1 depends only on its own step k, so nothing forces a device-wide barrier per step.
-    pipelined = None
-    if args.pipeline_groups > 1 and fused_agent and graph is not None and N % args.pipeline_groups == 0:
-        try:
-            H, n = args.pipeline_groups, N // args.pipeline_groups
-            genvs, gacts, gstreams = [], [], []
-            for h in range(H):
-                e = ea.VecEWN(n, board_size=args.board_size, cube_layer=args.cube_layer, opponent_policy=args.opponent,
-                              max_depth=args.max_depth, rng=args.rng, autoreset=True, lane_offset=lo + h * n, seed_stride=N * world,
-                              philox_key=2024, num_simulations=args.num_simulations, num_env_copies=args.num_env_copies,
-                              want_random_action=True)
-                e.reset(seeds=lane_seeds(lo + h * n, lo + (h + 1) * n).cuda())
-                e.sample_legal_actions(0, out=e.random_action)
-                genvs.append(e); gacts.append(e.random_action); gstreams.append(torch.cuda.Stream())
-            for _ in range(min(20, args.warmup)):
-                for e, a in zip(genvs, gacts):
-                    e.step(a)
-            torch.cuda.synchronize()
-            pgraph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(pgraph):
-                cur = torch.cuda.current_stream()
-                for st_ in gstreams:
-                    st_.wait_stream(cur)
-                for e, a, st_ in zip(genvs, gacts, gstreams):
-                    with torch.cuda.stream(st_):
-                        for _ in range(args.graph_steps):
-                            e.step(a)
-                for st_ in gstreams:
-                    cur.wait_stream(st_)
-            torch.cuda.synchronize()
-            reps = max(1, n_rep)
-            tp0 = time.perf_counter()
-            for _ in range(reps):
-                pgraph.replay()
-            torch.cuda.synchronize()
-            pdt = time.perf_counter() - tp0
-            pipelined = {"groups": H, "lanes_per_group": n, "value_this_rank": N * reps * args.graph_steps / pdt, "unit": "env steps/sec",
-                         "us_per_step_of_all_lanes": pdt / (reps * args.graph_steps) * 1e6,
-                         "note": "same lanes, %d groups on %d streams in one hipGraph, no barrier between the groups' steps; not the headline value" % (H, H)}
-            del pgraph, genvs, gacts
-        except Exception as exc:   # never let the extra measurement break the bench line
-            pipelined = {"error": repr(exc)[:200]}
-
-    # Dominant-kernel duration: the same K steps again, launched eagerly with a HIP event pair around every ewn_step on the
-    # launch stream (a graph replay cannot be bracketed per kernel).  rocprofv3 --kernel-trace of this command must agree.
-    kms = None
-    if not args.no_kernel_timing:
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-        for k in range(args.steps):
-            if not fused_agent:
-                env.sample_legal_actions(0, out=actions, step_tensor=counter)
-            ev[k][0].record()
-            env.step(actions)
-            ev[k][1].record()
-            if not fused_agent:
-                counter.add_(1)
-        torch.cuda.synchronize()
-        kms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    # ---- extras (N=1 only; clearly labelled, never `value`)
+    extras = {}
+    if world == 1 and not args.no_extras and not args.no_graph:
+        def extra(name, mode_, **kw):
+            try:
+                r = Runner(torch, make_env(), args, mode_, **kw)
+                steps = min(args.steps, 1000)
+                r.launch(min(args.warmup, 50))
+                d, evm = r.run(steps, barrier)
+                extras[name] = {"value": N * steps / d, "unit": "env steps/sec", "us_per_step": d / steps * 1e6,
+                                "event_us_per_step": evm * 1e3 / steps, "steps": steps}
+            except Exception as exc:   # never let an extra measurement break the bench line
+                extras[name] = {"error": repr(exc)[:200]}
+        if mode == "rollout":
+            extra("single_step_launch", "step")                  # round 1's headline: one ewn_step launch per env step
+            if not args.no_trajectory:
+                extra("rollout_without_trajectory", "rollout", trajectory=False)
+        if args.agent == "legal":
+            extra("agent_uniform_over_all_6_actions", "step", agent="uniform6")   # illegal-move terminations
 
     if rank == 0:
         total_steps = N * world * args.steps
         value = total_steps / dt
         bytes_per = ALGO_BYTES_PER_LANE_STEP.get(args.board_size, 2 * args.board_size ** 2 + 10)
-        roof = None
-        if kms is not None:
-            achieved = N * bytes_per / (kms * 1e-3) / 1e9
-            traffic = valu = None
-            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath) and N == 65536 and args.board_size == 5:
-                try:   # PMC results of this kernel at this size, collected by tools/pmc_passes.sh in separate rocprofv3 passes
-                    pmc = json.load(open(tpath))
-                    key = "%s_d%d_%s" % (args.opponent, args.max_depth, args.rng)
-                    traffic = pmc.get(key)
-                    vi = pmc.get(key + "_valu_wave_insts")
-                    if vi:   # the bound that actually binds: integer VALU issue, one wave-instruction per 4 cycles per SIMD
-                        peak = 1024 * 2.4e9 / 4
+        launches = runner.launches(args.steps)
+        steps_per_launch = args.steps / launches
+        kms = ev_ms / launches                                   # per ewn_step / ewn_step_k launch (launch gaps included)
+        algo = N * bytes_per * steps_per_launch
+        achieved = algo / (kms * 1e-3) / 1e9
+        traffic = valu = None
+        note = ""
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:   # PMC results of this kernel at this size, collected by tools/pmc_passes.sh in separate rocprofv3 passes
+                pmc = json.load(open(tpath))
+                ent = pmc.get(pmc_key(mode, args.opponent, args.max_depth, args.rng, args.board_size, N, runner.K, runner.trajectory))
+                if ent and pmc.get("source_hash") == source_hash():
+                    traffic = ent["hbm_bytes_per_launch"]
+                    vi, peak = ent.get("valu_wave_insts_per_launch"), pmc.get("valu_issue_peak_per_s")
+                    if vi and peak:
                         valu = {"wave_insts_per_launch": vi, "achieved_per_s": vi / (kms * 1e-3), "peak_per_s": peak,
-                                "frac": vi / (kms * 1e-3) / peak, "unit": "VALU wave-instructions/s (256 CUs x 4 SIMDs, 2.4 GHz, 4 cycles each)"}
-                except Exception:
-                    traffic = valu = None
-            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "valu_issue": valu, "kernel": "k_step (fused agent move + opponent search + reply + auto-reset)",
-                    "kernel_ms": kms, "algorithmic_bytes_per_launch": N * bytes_per,
-                    "note": "integer/fp64-compare search work: VALU-bound, far from the HBM roof by construction (SURVEY 8d)"}
+                                "frac": vi / (kms * 1e-3) / peak,
+                                "unit": "VALU wave-instructions/s; peak = 1024 SIMDs x clock / the measured issue cycles of this kernel's "
+                                        "instruction mix (tools/valu_probe.py, profiles/r02/valu_probe.json)"}
+                elif ent:
+                    note = "; profiles/pmc_traffic.json was collected on other kernel sources (hash mismatch): traffic not reported"
+            except Exception:
+                traffic = valu = None
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "valu_issue": valu,
+                "kernel": "k_rollout_d3 (K fused env steps per launch)" if mode == "rollout" else "k_step (fused agent move + opponent search + reply + auto-reset)",
+                "kernel_ms": kms, "env_steps_per_launch": steps_per_launch, "algorithmic_bytes_per_launch": algo,
+                "note": "integer/fp64-compare search work: VALU-bound, far from the HBM roof by construction (SURVEY 8d); kernel_ms = one HIP "
+                        "event pair on the launch stream around the timed region / launches" + note}
+        if mode == "rollout":
+            launch = "ewn_step_k: %d env steps per launch, %s; %s" % (
+                runner.K, "per-step trajectory (obs, action, reward, flags) written to HBM" if runner.trajectory else "no trajectory output",
+                "hipGraph replay" if not args.no_graph else "eager")
+        else:
+            launch = "one ewn_step launch per env step; " + ("hipGraph replay (%s)" % ", ".join("%d x %d steps" % (r, g) for g, r in runner.plan(args.steps))
+                                                             if not args.no_graph else "eager")
+        agent_txt = {"legal": "random-legal agent", "uniform6": "agent uniform over all 6 actions"}[args.agent]
         line = {
             "metric": "env steps/sec (whole node), 5x5 EWN, depth-3 expectiminimax opponent" if
                       (args.board_size == 5 and args.opponent == "minimax" and args.max_depth == 3) else
@@ -271,16 +381,18 @@ def main():
             "value": value, "unit": "env steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 bitboards (int8 boards in HBM), f64 expectation", "data": "synthetic",
-            "config": {"workload": ("%%dx%%d EWN, %%d parallel envs per GPU, %%s opponent%%s, random-legal agent (%s), auto-reset, %%s dice RNG"
-                                    % ("emitted by the step kernel" if fused_agent else "separate policy kernel"))
+            "config": {"workload": "%dx%d EWN, %d parallel envs per GPU, %s opponent%s, %s (in-engine), auto-reset, %s dice RNG"
                                    % (args.board_size, args.board_size, N, args.opponent,
-                                      " depth %d (hybrid heuristic)" % args.max_depth if args.opponent == "minimax" else "", args.rng),
+                                      " depth %d (%s heuristic)" % (args.max_depth, args.heuristic) if args.opponent == "minimax" else "",
+                                      agent_txt, args.rng),
                        "lanes_per_gpu": N, "board_size": args.board_size, "cube_layer": args.cube_layer,
-                       "opponent": args.opponent, "max_depth": args.max_depth, "rng": args.rng,
-                       "launch": "hipGraph replay (%d steps per graph)" % args.graph_steps if graph is not None else "eager",
+                       "opponent": args.opponent, "max_depth": args.max_depth, "rng": args.rng, "mode": mode, "launch": launch,
+                       "kernel_launches_in_timed_region": launches,
                        "parallelism": "lanes sharded across %d GPU(s), no data-path collective" % world},
-            "leaf_positions_per_sec": value * 108 if (args.opponent == "minimax" and args.max_depth == 3) else None,
-            "pipelined": pipelined,
+            "rccl_ranks": ranks_seen if args.backend == "nccl" else None,
+            "collective": {"backend": args.backend if world > 1 else None, "ranks": ranks_seen},
+            "state_digest": digest,
+            "extras": extras or None,
             "roofline": roof, "cpu_baseline": cpub,
         }
         print(json.dumps(line), flush=True)

@@ -7,7 +7,7 @@ import itertools
 
 import numpy as np
 
-from classical_policies.base import PolicyBase, obs_arrays
+from classical_policies.base import PolicyBase, obs_arrays, reference_ctor_side_effect
 
 
 class MctsAgent(PolicyBase):
@@ -20,6 +20,8 @@ class MctsAgent(PolicyBase):
         self.board_size = board_size
         self.num_simulations = num_simulations
         self.num_env_copies = num_env_copies
+        if kwargs.get("reference_quirks", True):
+            reference_ctor_side_effect(cube_layer)
         self.key = int(np.random.SeedSequence(seed).generate_state(2, np.uint32).view(np.uint64)[0])
 
     def predict_batch(self, boards, dice, return_wins=False):

@@ -4,7 +4,7 @@ runs the table-driven kernel of ewn_gym_amd/csrc/ewn_fast.hpp, other depths/heur
 the compile-time-unrolled recursion of ewn_core.hpp)."""
 import numpy as np
 
-from classical_policies.base import PolicyBase, obs_arrays
+from classical_policies.base import PolicyBase, obs_arrays, reference_ctor_side_effect
 
 
 class ExpectiMinimaxAgent(PolicyBase):
@@ -15,6 +15,8 @@ class ExpectiMinimaxAgent(PolicyBase):
         self.cube_layer = cube_layer
         self.board_size = board_size
         self.heuristic = heuristic
+        if kwargs.get("reference_quirks", True):
+            reference_ctor_side_effect(cube_layer)
         if heuristic == "sim_winrate":
             raise ewn_gym_amd.EwnError("heuristic 'sim_winrate' (envs/minimax_ewn.py:215-238) is not built")
 

@@ -20,6 +20,7 @@ except ImportError:  # pragma: no cover - depends on the image
     _Base = object
 
 VIEWPORT_SIZE = 700
+FONT_SIZE = VIEWPORT_SIZE // 25
 FPS = 30
 
 
@@ -114,6 +115,7 @@ class EinsteinWuerfeltNichtEnv(_Base):
         _, _, r, te, tr, info = self._engine.step(np.array([[int(a[0]), int(a[1])]], dtype=np.int8))
         self._pull()
         code = int(info[0].item())
+        self._engine.check_rng()      # an episode longer than the MT19937-compat stream supports must not pass silently
         msg = ewn_gym_amd.INFO_MESSAGES[code]
         if code == 5:
             msg = msg.format(int(self._engine.tolerance[0].item()))
@@ -192,8 +194,42 @@ class EinsteinWuerfeltNichtEnv(_Base):
             print(self.dice_roll)
             print("board:")
             print(self.board)
-        elif self.render_mode in ("human", "rgb_array"):
-            raise DependencyNotInstalled("pygame rendering (envs/ewn.py:503-569) is out of scope of the HIP engine")
+        elif self.render_mode == "rgb_array":
+            return self._render_rgb()
+        elif self.render_mode == "human":
+            raise DependencyNotInstalled("the pygame window (envs/ewn.py:503-569) is not built; use render_mode='rgb_array' or 'ansi'")
+
+    def _render_rgb(self):
+        """The frame envs/ewn.py:520-569 draws with pygame, drawn with PIL ('rgb via PIL only if pygame absent'):
+        same geometry and colours -- (VIEWPORT_SIZE + FONT_SIZE) x VIEWPORT_SIZE x 3 uint8, board colour (211, 179, 104), grid
+        lines every VIEWPORT_SIZE // S pixels, TOP_LEFT cubes white / BOTTOM_RIGHT black discs of radius 0.4 cells with the
+        cube number, "dice: n" under the board.  Glyph rasterisation differs from SDL's, nothing else."""
+        try:
+            from PIL import Image, ImageDraw, ImageFont
+        except ImportError as e:   # pragma: no cover
+            raise DependencyNotInstalled("rgb_array rendering needs Pillow") from e
+        S = self.board.shape[0]
+        img = Image.new("RGB", (VIEWPORT_SIZE, VIEWPORT_SIZE + FONT_SIZE), (211, 179, 104))
+        dr = ImageDraw.Draw(img)
+        try:
+            font = ImageFont.load_default(size=FONT_SIZE * 3 // 4)
+        except TypeError:          # pragma: no cover - old Pillow
+            font = ImageFont.load_default()
+        dr.text((0, VIEWPORT_SIZE), "dice: %s" % self.dice_roll, fill=(0, 0, 0), font=font)
+        lw = VIEWPORT_SIZE // S
+        for i in range(1, S):
+            dr.line([(0, i * lw), (VIEWPORT_SIZE, i * lw)], fill=(0, 0, 0))
+            dr.line([(i * lw, 0), (i * lw, VIEWPORT_SIZE)], fill=(0, 0, 0))
+        dr.line([(0, VIEWPORT_SIZE), (VIEWPORT_SIZE, VIEWPORT_SIZE)], fill=(0, 0, 0))
+        rad = int(lw * 0.4)
+        for (x, y), cube in np.ndenumerate(self.board):
+            if cube == 0:
+                continue
+            color, text_color = ((255, 255, 255), (0, 0, 0)) if cube > 0 else ((0, 0, 0), (255, 255, 255))
+            cx, cy = int((y + 0.5) * lw), int((x + 0.5) * lw)
+            dr.ellipse([cx - rad, cy - rad, cx + rad, cy + rad], fill=color, outline=color)
+            dr.text((cx - FONT_SIZE // 3, cy - FONT_SIZE // 2), str(abs(int(cube))), fill=text_color, font=font)
+        return np.asarray(img, dtype=np.uint8)
 
     def close(self):
         pass

@@ -151,9 +151,12 @@ class A2CTrainer:
         self.opt = torch.optim.RMSprop(self.model.parameters(), lr=learning_rate, alpha=0.99, eps=1e-5)
         self.n_steps, self.gamma, self.gae_lambda = n_steps, gamma, gae_lambda
         self.ent_coef, self.vf_coef, self.max_grad_norm = ent_coef, vf_coef, max_grad_norm
+        # the sampling noise must differ between ranks (each owns different lanes): the generator is keyed by the global id
+        # of this rank's first lane, NOT by the seed alone (which seeds the identical parameters on every rank)
         self.gen = torch.Generator(device=self.device)
-        if seed is not None:
-            self.gen.manual_seed(seed + 7919 * getattr(env, "lane_offset", 0))
+        cfg = getattr(env, "cfg", None)
+        self.lane_offset = int(getattr(cfg, "lane_offset", getattr(env, "lane_offset", 0)))
+        self.gen.manual_seed((0 if seed is None else int(seed)) + 7919 * (self.lane_offset + 1))
         self.num_timesteps = 0
         # rollout storage, allocated once: [T, N, ...]
         T, N, S = n_steps, env.N, env.S
@@ -165,6 +168,7 @@ class A2CTrainer:
         self._rews = torch.zeros((T, N), dtype=torch.float32, device=dev)
         self._dones = torch.zeros((T, N), dtype=torch.float32, device=dev)
         self._graph = None
+        self._warm = False
         self.use_graph = use_graph and self.device.type == "cuda"
 
     def _rollout(self):
@@ -173,7 +177,7 @@ class A2CTrainer:
         for t in range(self.n_steps):
             self._boards[t].copy_(env.board)
             self._dices[t].copy_(env.dice)
-            a, v = self.model.act(env.board, env.dice)
+            a, v = self.model.act(env.board, env.dice, generator=self.gen)
             self._acts[t].copy_(a)
             self._vals[t].copy_(v)
             _, _, r, term, _, _ = env.step(self._acts[t])
@@ -188,21 +192,21 @@ class A2CTrainer:
 
     def collect_and_update(self):
         env, T, N = self.env, self.n_steps, self.env.N
-        if self.use_graph:
+        if self.use_graph and self._warm:
             # the whole n-step rollout (policy forward, sampling, ewn_step, bookkeeping) is one captured hipGraph: the
-            # policy net is ~13 k parameters, so un-captured the loop is pure launch overhead (~25 tiny kernels per step)
+            # policy net is ~13 k parameters, so un-captured the loop is pure launch overhead (~25 tiny kernels per step).
+            # The FIRST rollout ran eagerly (it is the warm-up capture needs, and its transitions are trained on like any
+            # other: no env step is thrown away); capturing executes nothing.
             if self._graph is None:
                 torch.cuda.synchronize()
-                side = torch.cuda.Stream()
-                with torch.cuda.stream(side):
-                    self._rollout()          # warm-up outside capture (lazy inits)
-                side.synchronize()
                 self._graph = torch.cuda.CUDAGraph()
+                self._graph.register_generator_state(self.gen)
                 with torch.cuda.graph(self._graph):
                     self._rollout()
             self._graph.replay()
         else:
             self._rollout()
+            self._warm = True
         with torch.no_grad():
             _, _, last_value = self.model(env.board, env.dice)
         rews, dones, vals = self._rews, self._dones, self._vals

@@ -68,6 +68,7 @@ def evaluate(agent, opponent, num=1024, board_size=5, cube_layer=3, rng="mt19937
         just = alive & (terminated != 0)
         score = torch.where(just, reward, score)
         length += alive.to(torch.int32)
+    env.check_rng()
     wins = int((score > 0).sum().item())
     lo, hi = wilson(wins, num)
     return {"scores": score, "lengths": length, "wins": wins, "episodes": num, "win_rate": wins / num,

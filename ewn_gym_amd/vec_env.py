@@ -42,7 +42,8 @@ def search_tables(board_size, cube_layer, device):
         if n > 0:
             host = np.zeros(n, dtype=np.uint8)
             check(lib.ewn_build_tables(key[0], key[1], host.ctypes.data_as(C.c_void_p)), "ewn_build_tables")
-            t = torch.from_numpy(host).to(device)
+            t = torch.zeros(n, dtype=torch.uint8, device=device)   # torch.zeros: the guard-zone test wraps this allocator
+            t.copy_(torch.from_numpy(host))
         _TABLES[key] = t
     return _TABLES[key]
 
@@ -124,6 +125,25 @@ class VecEWN:
                                           _ptr(step_tensor), int(self.cfg.lane_offset), _ptr(out), _stream()),
               "ewn_predict_random")
         return out
+
+    def rng_overflow(self):
+        """uint8 [N]: lanes whose current episode has consumed more MT19937 draws than the closed form covers (454; see
+        DESIGN.md section 3) -- from then on their dice are NOT numpy's.  Always zero for the Philox kind."""
+        if self.cfg.rng_kind != RNG["mt19937"]:
+            return torch.zeros(self.N, dtype=torch.uint8, device=self.device)
+        return (self.rng_state.view(-1)[3:4 * self.N:4] & 1).to(torch.uint8)
+
+    def check_rng(self):
+        """Raise if any lane ran past the MT19937-compat stream (one device reduction + sync: call it where a host sync
+        happens anyway -- the N=1 drop-in env does so every step, tournament.evaluate once per evaluation)."""
+        if self.cfg.rng_kind == RNG["mt19937"] and bool(self.rng_overflow().any()):
+            lanes = torch.nonzero(self.rng_overflow()).reshape(-1)[:8].tolist()
+            raise _lib.EwnError("MT19937-compat dice stream exhausted (>= 454 draws in one episode) on lanes %s: results are no "
+                                "longer bit-identical to numpy's stream; use rng='philox' for such long games" % lanes)
+
+    def supports_rollout(self):
+        """True when ewn_step_k (K env steps per launch, in-engine agent) exists for this configuration"""
+        return False
 
     def set_obs(self, boards, dice):
         """Overwrite the observation of every lane (agent = TOP_LEFT to move); RNG state is kept."""

@@ -102,3 +102,34 @@ def test_split_k_linear_matches_nn_linear():
     assert torch.allclose(a.bias.grad, b.bias.grad, rtol=1e-4, atol=1e-3)
     small = torch.randn(16, 32)
     assert torch.equal(a(small), b(small))
+
+
+class _FakeEnv:
+    """CPU stand-in with VecEWN's attribute surface (the real engine needs a GPU): fixed observation, zero reward"""
+
+    def __init__(self, n, lane_offset):
+        import types
+        self.N, self.S, self.cube_num = n, 5, 6
+        self.cfg = types.SimpleNamespace(lane_offset=lane_offset)
+        self.board = torch.zeros((n, 5, 5), dtype=torch.int8)
+        self.dice = torch.ones(n, dtype=torch.int8)
+        self._r = torch.zeros(n, dtype=torch.float64)
+        self._t = torch.zeros(n, dtype=torch.uint8)
+
+    def step(self, a):
+        return self.board, self.dice, self._r, self._t, self._t, self._t
+
+
+def test_ranks_share_parameters_but_not_sampling_noise():
+    """Every rank seeds the same parameters (then broadcast), but the exploration noise is keyed by the rank's first global
+    lane: two shards of one job must not draw the same Gumbel noise (perfectly correlated exploration)."""
+    from ewn_gym_amd.a2c import A2CTrainer
+    a = A2CTrainer(_FakeEnv(64, 0), n_steps=3, seed=5, use_graph=False)
+    b = A2CTrainer(_FakeEnv(64, 64), n_steps=3, seed=5, use_graph=False)
+    a2 = A2CTrainer(_FakeEnv(64, 0), n_steps=3, seed=5, use_graph=False)
+    for p, q in zip(a.model.parameters(), b.model.parameters()):
+        assert torch.equal(p, q)
+    for t in (a, b, a2):
+        t._rollout()
+    assert torch.equal(a._acts, a2._acts)          # same shard, same seed: reproducible
+    assert not torch.equal(a._acts, b._acts)       # other shard: other noise

@@ -226,3 +226,46 @@ def test_sim_winrate_heuristic_statistics(golden):
     env.board[:] = boards[0]
     v = env.evaluate("sim_winrate")
     assert 0.0 <= v <= 1.0
+
+
+def test_rgb_array_render_and_ctor_side_effect():
+    """render_mode='rgb_array' (envs/ewn.py:503-569) drawn with PIL: frame geometry and colours of the reference's surface;
+    and the reference's ctor side effect on the global numpy stream: building a search policy re-seeds it
+    to 9487 and consumes one dice draw."""
+    import envs
+    from classical_policies import ExpectiMinimaxAgent, MctsAgent
+    env = envs.EinsteinWuerfeltNichtEnv(render_mode="rgb_array")
+    env.reset(seed=3)
+    frame = env.render()
+    assert frame.shape == (700 + 28, 700, 3) and frame.dtype == np.uint8
+    lw = 700 // 5
+    assert tuple(frame[lw * 2 + lw // 2, lw * 2 + lw // 2]) == (211, 179, 104)          # cell (2, 2) is empty: board colour
+    assert tuple(frame[lw // 2, lw // 2 - 45]) == (255, 255, 255)                        # TOP_LEFT cube 1 at (0, 0): white disc
+    assert tuple(frame[4 * lw + lw // 2, 4 * lw + lw // 2 - 45]) == (0, 0, 0)            # BOTTOM_RIGHT cube at (4, 4): black disc
+    assert tuple(frame[lw, 300]) == (0, 0, 0)                                            # a grid line
+    for make in (lambda: ExpectiMinimaxAgent(max_depth=2, cube_layer=3, board_size=5), lambda: MctsAgent(cube_layer=3, board_size=5)):
+        np.random.seed(1)
+        make()
+        got = np.random.randint(0, 1 << 30, 4).tolist()
+        np.random.seed(9487)
+        np.random.randint(1, 7)
+        assert got == np.random.randint(0, 1 << 30, 4).tolist()
+
+
+def test_mt_stream_exhaustion_is_reported():
+    """MT19937-compat dice are numpy's only for the first 454 draws of an episode; past that the lane is flagged and
+    VecEWN.check_rng() raises instead of silently playing wrong dice."""
+    import ewn_gym_amd as ea
+    env = ea.VecEWN(64, rng="mt19937", mt_window=16)
+    env.reset(seeds=np.arange(64))
+    env.check_rng()
+    env.rng_state.view(-1)[1:4 * 64:4] = 453          # draw index of every lane: the next draws are numbers 453, 454, ...
+    for t in range(2):
+        env.step(env.sample_legal_actions(t))
+    assert bool(env.rng_overflow().any())
+    with pytest.raises(ea.EwnError, match="MT19937"):
+        env.check_rng()
+    ok = ea.VecEWN(64, rng="philox")
+    ok.reset(seeds=np.arange(64))
+    ok.step(ok.sample_legal_actions(0))
+    ok.check_rng()

@@ -621,6 +621,23 @@ def test_no_kernel_writes_outside_its_buffers(ea, monkeypatch):
              dict(n=257, opponent_policy="minimax", max_depth=3, rng="philox"), dict(n=40000, opponent_policy="minimax", max_depth=3, rng="mt19937"),
              dict(n=100, opponent_policy="mcts", num_simulations=3, num_env_copies=2, rng="philox"),
              dict(n=70, opponent_policy="minimax", max_depth=2, heuristic="attk", rng="mt19937", board_size=7, cube_layer=4)]
+    # the cached table images are handed to the C ABI too (and were the buffer the r01 overrun landed in): rebuild them
+    # through the guarded allocator; their guards are checked after every case below and the cache is dropped at the end
+    saved_tables = dict(vec_env._TABLES)
+    vec_env._TABLES.clear()
+    monkeypatch.setattr(vec_env.torch, "zeros", guarded_zeros)
+    try:
+        for (S, L) in ((5, 3), (7, 3), (6, 3), (8, 3)):
+            assert vec_env.search_tables(S, L, torch.device("cuda")) is not None
+    finally:
+        monkeypatch.setattr(vec_env.torch, "zeros", real_zeros)
+    table_guards = list(guarded)
+    guarded.clear()
+    assert len(table_guards) == 4
+
+    def tables_intact():
+        return all(bool((buf[:G] == 0xA5).all()) and bool((buf[G + pad:] == 0xA5).all()) for buf, pad in table_guards)
+
     for kw in cases:
         kw = dict(kw)
         n = kw.pop("n")
@@ -635,6 +652,7 @@ def test_no_kernel_writes_outside_its_buffers(ea, monkeypatch):
         torch.cuda.synchronize()
         for buf, pad in guarded:
             assert bool((buf[:G] == 0xA5).all()) and bool((buf[G + pad:] == 0xA5).all()), kw
+        assert tables_intact(), kw
         guarded.clear()
     # the stateless queries allocate their outputs with torch.zeros too
     for (S, L, M) in ((5, 3, 1), (5, 3, 63), (7, 3, 1000), (8, 5, 77), (6, 4, 130)):
@@ -653,4 +671,7 @@ def test_no_kernel_writes_outside_its_buffers(ea, monkeypatch):
         torch.cuda.synchronize()
         for buf, pad in guarded:
             assert bool((buf[:G] == 0xA5).all()) and bool((buf[G + pad:] == 0xA5).all()), (S, L, M)
+        assert tables_intact(), (S, L, M)
         guarded.clear()
+    vec_env._TABLES.clear()
+    vec_env._TABLES.update(saved_tables)

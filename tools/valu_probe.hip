@@ -1,0 +1,140 @@
+// valu_probe.hip -- measures the issue cost of the instruction classes the EWN step kernels are made of, on gfx950, at 1, 2, 4
+// and 8 waves per SIMD.  Not product code: a measurement tool (tools/valu_probe.py builds and drives it and writes
+// profiles/r02/valu_probe.json, from which bench.py's roofline.valu_issue takes its measured peak).
+//
+// Method: every wave runs `reps` x (32 instructions of ONE class on 8 independent registers) between two s_memtime reads
+// (s_memtime ticks at the shader clock, MI355X_MICROARCH.md constants table); a block is 256 threads = one wave per SIMD of
+// its CU, and the requested LDS size makes exactly W blocks fit a CU, so W = waves per SIMD.  While the SIMD's issue port is
+// the bottleneck, issue cycles per wave-instruction = wave cycles / instructions / W.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+
+typedef unsigned long long u64;
+typedef uint32_t u32;
+
+#define CLASSES(X) \
+    X(v_xor_b32,      32, "v_xor_b32 %0, %0, %1") \
+    X(v_and_or_b32,   32, "v_and_or_b32 %0, %0, %1, %1") \
+    X(v_lshlrev_b32,  32, "v_lshlrev_b32 %0, 1, %0") \
+    X(v_add_u32,      32, "v_add_u32 %0, %0, %1") \
+    X(v_lshl_or_b32,  32, "v_lshl_or_b32 %0, %0, 1, %1") \
+    X(v_xad_u32,      32, "v_xad_u32 %0, %0, %1, %1") \
+    X(v_min_u32,      32, "v_min_u32 %0, %0, %1") \
+    X(v_perm_b32,     32, "v_perm_b32 %0, %0, %1, %1") \
+    X(v_ffbh_u32,     32, "v_ffbh_u32 %0, %0") \
+    X(v_bcnt_u32_b32, 32, "v_bcnt_u32_b32 %0, %0, %1") \
+    X(v_mad_u32_u24,  32, "v_mad_u32_u24 %0, %0, %1, %1") \
+    X(v_mul_lo_u32,   32, "v_mul_lo_u32 %0, %0, %1") \
+    X(v_mul_hi_u32,   32, "v_mul_hi_u32 %0, %0, %1") \
+    X(v_cndmask_b32,  32, "v_cndmask_b32 %0, %0, %1, vcc") \
+    X(v_cmp_lt_u32,   32, "v_cmp_lt_u32 vcc, %0, %1") \
+    X(v_mov_b32,      32, "v_mov_b32 %0, %1") \
+    X(v_mov_b32_dpp,  32, "v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") \
+    X(v_lshlrev_b64,  64, "v_lshlrev_b64 %0, 1, %0") \
+    X(v_lshrrev_b64,  64, "v_lshrrev_b64 %0, 1, %0") \
+    X(v_add_f64,      -64, "v_add_f64 %0, %0, %1") \
+    X(v_mul_f64,      -64, "v_mul_f64 %0, %0, %1") \
+    X(v_max_f64,      -64, "v_max_f64 %0, %0, %1") \
+    X(v_cmp_le_f64,   -64, "v_cmp_le_f64 vcc, %0, %1")
+
+enum {
+#define X(name, w, ins) OP_##name,
+    CLASSES(X)
+#undef X
+    OP_N
+};
+
+struct ClassInfo { const char *name; int width; };
+static const ClassInfo INFO[OP_N] = {
+#define X(name, w, ins) { #name, w },
+    CLASSES(X)
+#undef X
+};
+
+#define ONE(ins, reg, kk) asm volatile(ins : "+v"(reg) : "v"(kk) : "vcc")
+#define ROW(ins, r0, r1, r2, r3, r4, r5, r6, r7, kk) ONE(ins, r0, kk); ONE(ins, r1, kk); ONE(ins, r2, kk); ONE(ins, r3, kk); ONE(ins, r4, kk); ONE(ins, r5, kk); ONE(ins, r6, kk); ONE(ins, r7, kk)
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_probe(u64 *out, int reps, u32 seed)
+{
+    u32 a0 = threadIdx.x + seed, a1 = a0 * 3u + 1u, a2 = a0 * 5u + 2u, a3 = a0 * 7u + 3u, a4 = a0 ^ 0x55u, a5 = a0 + 77u, a6 = a0 * 11u, a7 = a0 | 0x100u;
+    u32 k = seed | 1u;
+    u64 b0 = a0, b1 = a1, b2 = a2, b3 = a3, b4 = a4, b5 = a5, b6 = a6, b7 = a7;
+    double d0 = a0, d1 = a1, d2 = a2, d3 = a3, d4 = a4, d5 = a5, d6 = a6, d7 = a7, dk = 1.0 + seed;
+    __syncthreads();
+    const u64 t0 = __builtin_amdgcn_s_memtime();
+    #pragma unroll 1
+    for (int r = 0; r < reps; r++) {
+#define X(name, w, ins) \
+        if constexpr (OP == OP_##name) { \
+            _Pragma("unroll") for (int q = 0; q < 4; q++) { \
+                if constexpr (w == 32) { ROW(ins, a0, a1, a2, a3, a4, a5, a6, a7, k); } \
+                else if constexpr (w == 64) { ROW(ins, b0, b1, b2, b3, b4, b5, b6, b7, k); } \
+                else { ROW(ins, d0, d1, d2, d3, d4, d5, d6, d7, dk); } \
+            } \
+        }
+        CLASSES(X)
+#undef X
+    }
+    const u64 t1 = __builtin_amdgcn_s_memtime();
+    const u32 sink = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ (u32)(b0 ^ b1 ^ b2 ^ b3 ^ b4 ^ b5 ^ b6 ^ b7) ^ (u32)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);
+    if ((threadIdx.x & 63) == 0) out[2 + blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+    if (sink == 0x12345678u) out[1] = sink; // keeps the chains alive
+}
+
+typedef void (*probe_fn)(u64 *, int, u32);
+static probe_fn FN[OP_N] = {
+#define X(name, w, ins) k_probe<OP_##name>,
+    CLASSES(X)
+#undef X
+};
+
+int main(int argc, char **argv)
+{
+    const int reps = argc > 1 ? atoi(argv[1]) : 2000;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, 0) != hipSuccess) { fprintf(stderr, "no GPU\n"); return 1; }
+    const int cus = prop.multiProcessorCount;
+    const size_t lds_cu = 160 * 1024;
+    u64 *dev = nullptr;
+    const int max_waves = cus * 8 * 4;
+    if (hipMalloc(&dev, (size_t)(2 + max_waves) * sizeof(u64)) != hipSuccess) return 1;
+    std::vector<u64> host(2 + max_waves);
+    printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz\": %d, \"reps\": %d, \"insts_per_wave\": %d, \"classes\": {\n", prop.gcnArchName, cus,
+           prop.clockRate / 1000, reps, reps * 32);
+    for (int op = 0; op < OP_N; op++) {
+        printf("  \"%s\": {\"width\": %d", INFO[op].name, INFO[op].width < 0 ? 64 : INFO[op].width);
+        for (int W = 1; W <= 8; W *= 2) {
+            // W blocks per CU: each asks for a 1/W share of the CU's LDS (minus slack for W = 1 is not needed: one block per
+            // CU is forced by asking for more than half)
+            const size_t lds = W == 1 ? 96 * 1024 : lds_cu / W - 512;
+            const int blocks = cus * W;
+            hipFuncSetAttribute((const void *)FN[op], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipMemset(dev, 0, (size_t)(2 + max_waves) * sizeof(u64));
+            hipLaunchKernelGGL(FN[op], dim3(blocks), dim3(256), lds, 0, dev, 64, 1u); // warm-up (code cache)
+            hipDeviceSynchronize();
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0); hipEventCreate(&e1);
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(FN[op], dim3(blocks), dim3(256), lds, 0, dev, reps, 1u);
+            hipEventRecord(e1, 0);
+            if (hipDeviceSynchronize() != hipSuccess) { fprintf(stderr, "launch failed\n"); return 1; }
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            hipMemcpy(host.data(), dev, (size_t)(2 + blocks * 4) * sizeof(u64), hipMemcpyDeviceToHost);
+            std::vector<u64> c(host.begin() + 2, host.begin() + 2 + blocks * 4);
+            std::sort(c.begin(), c.end());
+            const double med = (double)c[c.size() / 2], insts = (double)reps * 32.0;
+            printf(", \"w%d\": {\"wave_cycles_per_inst\": %.3f, \"issue_cycles_per_inst\": %.3f, \"kernel_ms\": %.4f}", W, med / insts, med / insts / W, ms);
+        }
+        printf("}%s\n", op + 1 < OP_N ? "," : "");
+    }
+    printf("}}\n");
+    hipFree(dev);
+    return 0;
+}
