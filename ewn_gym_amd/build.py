@@ -1,16 +1,20 @@
-"""Build libewn_hip.so (gfx950) in-tree with hipcc.  `python -m ewn_gym_amd.build`."""
+"""Build libewn_hip.so (gfx950) in-tree with hipcc.  `python -m ewn_gym_amd.build`.
+
+The library is several translation units (csrc/*.hip) compiled in parallel to objects and linked once: the kernel
+template instantiations (board size x lanes per game x opponent x RNG kind) dominate the build time."""
 import os
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, "csrc", "ewn_kernels.hip")]
-DEPS = [os.path.join(HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(HERE, "csrc")))] + \
-       [os.path.join(HERE, "..", "include", "ewn_hip.h")]
+CSRC = os.path.join(HERE, "csrc")
+SRC = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+DEPS = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(HERE, "..", "include", "ewn_hip.h")]
 OUT = os.path.join(HERE, "lib", "libewn_hip.so")
+OBJ = os.path.join(HERE, "lib", "obj")
 # -ffp-contract=off: the fp64 heuristic and expectation sums must round exactly like the
 # reference's Python floats (no FMA contraction); no fast-math anywhere.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 
 
 def stale():
@@ -24,8 +28,24 @@ def build(force=False, verbose=False):
     if not force and not stale():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [hipcc] + FLAGS + ["-o", OUT] + SRC
+    os.makedirs(OBJ, exist_ok=True)
+    extra = os.environ.get("EWN_HIPCC_FLAGS", "").split()
+    jobs = []
+    for src in SRC:
+        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+        cmd = [hipcc] + FLAGS + extra + ["-c", "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        jobs.append((subprocess.Popen(cmd), obj, cmd))
+    objs = []
+    for p, obj, cmd in jobs:
+        if p.wait() != 0:
+            for q, _, _ in jobs:
+                if q.poll() is None:
+                    q.kill()
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

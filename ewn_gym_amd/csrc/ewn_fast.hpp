@@ -55,6 +55,9 @@ struct FastTab {
     // moves make up the legal list in the reference's order; 6 = none (byte 6 of a position word is permanently off board)
     uint16_t sel[512];
     uint8_t nth[512];                            // [6-bit legal mask * 8 + k] -> index of its k-th set bit (0 when there is none)
+    // ring index -> ring index of the same square seen from the other side (board rotated by 180 degrees, envs/ewn.py:289-296);
+    // an involution.  The rollout kernel uses it to hand the AGENT's position to the same search (ewn_rollout.hpp).
+    uint8_t rot[64];
 };
 
 // LDS / device image size: the struct padded to 4 KiB so the LDS-DMA copy needs no tail handling
@@ -138,6 +141,7 @@ static int build_fast_tables(FastTab<S> *T, int variant = 0)
         T->nth[e] = (uint8_t)(m ? j : 0);
     }
     for (int q = 0; q < 64; q++) T->real_of_ring[q] = q < S * S ? (uint8_t)(S * S - 1 - rm_of_ring[q]) : 0;
+    for (int q = 0; q < 64; q++) T->rot[q] = q < S * S ? (uint8_t)ring_of_rm[S * S - 1 - rm_of_ring[q]] : 0;
     T->init_posP = T->init_posN = 0x4040ull << 48; // bytes 6 and 7: no such cube
     {
         int cnt = 1;

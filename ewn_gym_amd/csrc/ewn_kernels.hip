@@ -7,81 +7,12 @@
 // rng u32 (headers [N][4], then for the MT kind windows [N][3][W] and epochs [N]).  In these generic kernels one thread
 // owns one lane (game); the wavefront is the unit of scheduling, not the unit of work -- a 25-cell board would leave
 // 39 of 64 lanes idle if a whole wavefront served one game.
-#include "ewn_core.hpp"
-#include "ewn_fast.hpp"
+#include "ewn_host.hpp"
 #include "ewn_playout.hpp"
-#include "../../include/ewn_hip.h"
-#include <cstdlib>
 
-#define BS 256
-
-struct KCfg {
-    int N, opp, depth, heur, rng_kind, shaped, autoreset, refresh, lane_offset, nsim_total;
-    u32 seed_stride, W, rng_words;
-    double reward, illegal_reward;
-    u64 key;
-};
-
-struct KState {
-    int8_t *board; int8_t *dice; uint8_t *done; u32 *rng; double *prev_score; int32_t *tolerance; const void *tables;
-};
-
-struct KOut {
-    double *reward; uint8_t *terminated; uint8_t *truncated; uint8_t *info; int8_t *tboard; int8_t *tdice; int8_t *ract;
-};
-
-struct KScratch { // split-phase step (MCTS opponent)
-    uint8_t *phase; int8_t *cboard; int8_t *cdice; int8_t *act; int32_t *wins; u32 *obs_id;
-};
-
-// ---------------------------------------------------------------- LDS staging
-
-// Copy nbytes between global and LDS with the whole block: 16-byte vectors when both
-// sides allow it (consecutive threads -> consecutive 16-byte pieces), then dwords, then
-// the byte tail.  All loads of a pass are issued before the first LDS store.
-__device__ __forceinline__ void block_copy_in(int8_t *lds, const int8_t *g, int nbytes)
-{
-    const int nq = (((uintptr_t)g & 15) == 0) ? nbytes >> 4 : 0;
-    for (int i = threadIdx.x; i < nq; i += blockDim.x) ((uint4 *)lds)[i] = ((const uint4 *)g)[i];
-    const int w0 = nq << 2, nw = (((uintptr_t)g & 3) == 0) ? nbytes >> 2 : w0;
-    for (int i = w0 + threadIdx.x; i < nw; i += blockDim.x) ((u32 *)lds)[i] = ((const u32 *)g)[i];
-    for (int i = (nw << 2) + threadIdx.x; i < nbytes; i += blockDim.x) lds[i] = g[i];
-}
-
-__device__ __forceinline__ void block_copy_out(int8_t *g, const int8_t *lds, int nbytes)
-{
-    const int nq = (((uintptr_t)g & 15) == 0) ? nbytes >> 4 : 0;
-    for (int i = threadIdx.x; i < nq; i += blockDim.x) ((uint4 *)g)[i] = ((const uint4 *)lds)[i];
-    const int w0 = nq << 2, nw = (((uintptr_t)g & 3) == 0) ? nbytes >> 2 : w0;
-    for (int i = w0 + threadIdx.x; i < nw; i += blockDim.x) ((u32 *)g)[i] = ((const u32 *)lds)[i];
-    for (int i = (nw << 2) + threadIdx.x; i < nbytes; i += blockDim.x) g[i] = lds[i];
-}
-
-// Search tables, global -> LDS with the LDS-DMA form of the load (global_load_lds_dwordx4):
-// no VGPR staging and nothing waits on it until the barrier in front of the search.
-// BYTES is a multiple of 4096 (256 threads x 16 B); src 16-byte aligned; dst = wave-uniform
-// base + lane*16, which is exactly the linear image we want.
-template <int BYTES>
-__device__ __forceinline__ void tables_to_lds(int8_t *lds, const int8_t *g)
-{
-    static_assert(BYTES % (BS * 16) == 0, "table size must be padded to 4 KiB");
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    #pragma unroll
-    for (int cnk = 0; cnk < BYTES / (BS * 16); cnk++) {
-        const int off = (cnk * (BS / 64) + wave) * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + off + lane * 16),
-                                         (__attribute__((address_space(3))) void *)(lds + off), 16, 0, 0);
-    }
-}
-
-// The LDS-DMA loads above are outstanding vector-memory operations of the wave that issued them; a barrier does not wait for
-// them.  Every wave must drain its own before the block barrier behind which OTHER waves read the chunks it fetched -- a
-// wave with no other load to wait for (all its lanes past the end of the batch, or simply faster) otherwise lets the rest
-// of the block read whatever the previous kernel left in that part of LDS (seen as wrong moves on one board size, only
-// after kernels for other board sizes had run on the same CUs).
-__device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
+#include "ewn_lds.hpp"
 #include "ewn_step_d3.hpp"
+#include "ewn_rollout.hpp"
 
 // ---------------------------------------------------------------- per-lane pieces
 
@@ -677,101 +608,6 @@ __global__ __launch_bounds__(BS) void k_mcts_pick(Geom g, int M, const int8_t *b
 
 // ---------------------------------------------------------------- host side: C ABI
 
-static bool make_geom(int S, int L, Geom &g)
-{
-    if (S < 3 || S > EWN_MAX_BOARD || L < 1 || L >= S - 1) return false; // assert cube_layer < board_size - 1, envs/ewn.py:47
-    const int CN = L * (L + 1) / 2;
-    if (CN > EWN_MAX_CUBES) return false;
-    g.S = S; g.L = L; g.CN = CN; g.cells = S * S;
-    g.not_lastcol = g.not_lastrow = g.not_firstcol = g.not_firstrow = 0;
-    for (int t = 0; t < 8; t++) g.sq[t] = 0;
-    for (int i = 0; i < S; i++)
-        for (int j = 0; j < S; j++) {
-            const u64 b = 1ull << (i * S + j);
-            if (j < S - 1) g.not_lastcol |= b;
-            if (i < S - 1) g.not_lastrow |= b;
-            if (j > 0) g.not_firstcol |= b;
-            if (i > 0) g.not_firstrow |= b;
-            for (int t = 0; t < S; t++) if (i >= t && j >= t) g.sq[t] |= b;
-        }
-    g.corner_br = 1ull << (S * S - 1);
-    for (int c = 0; c < 64; c++) g.init[c] = 0;
-    int cnt = 1;
-    for (int i = 1; i <= L; i++)
-        for (int j = 0; j < i; j++) {
-            g.init[j * S + (i - j - 1)] = (int8_t)cnt;
-            g.init[(S - 1 - j) * S + (S - i + j)] = (int8_t)(-cnt);
-            cnt++;
-        }
-    g.init_occP = g.init_occN = 0; g.init_alive = 0;
-    for (int w = 0; w < 2; w++) g.init_posP[w] = g.init_posN[w] = 0;
-    for (int c = 0; c < S * S; c++) {
-        const int v = g.init[c];
-        if (v > 0) { g.init_occP |= 1ull << c; g.init_alive |= 1u << (v - 1); g.init_posP[(v - 1) / 10] |= (u64)c << (6 * ((v - 1) % 10)); }
-        if (v < 0) { g.init_occN |= 1ull << c; g.init_posN[(-v - 1) / 10] |= (u64)c << (6 * ((-v - 1) % 10)); }
-    }
-    return true;
-}
-
-static int check_cfg(const ewn_config *cfg, Geom &g, KCfg &k)
-{
-    if (!cfg) return EWN_ENULL;
-    if (cfg->board_size > EWN_MAX_BOARD && cfg->cube_layer >= 1 && cfg->cube_layer < cfg->board_size - 1) return EWN_EUNSUPPORTED;
-    if (!make_geom(cfg->board_size, cfg->cube_layer, g)) return EWN_EINVAL;
-    if (cfg->n_lanes < 1) return EWN_EINVAL;
-    if (cfg->opponent_kind < 0 || cfg->opponent_kind > EWN_OPP_MCTS) return EWN_EINVAL;
-    if (cfg->rng_kind != EWN_RNG_MT19937 && cfg->rng_kind != EWN_RNG_PHILOX) return EWN_EINVAL;
-    if (cfg->opponent_kind == EWN_OPP_MINIMAX) {
-        if (cfg->max_depth < 1 || cfg->max_depth > EWN_MAX_DEPTH) return EWN_EUNSUPPORTED;
-        if (cfg->heuristic < 0 || cfg->heuristic > EWN_H_ATTK) return EWN_EUNSUPPORTED;
-    }
-    // the searches and rollouts roll dice 1..6 (minimax.py:68, mcts.py:29): cube_num < 6 raises IndexError upstream
-    if (cfg->opponent_kind != EWN_OPP_RANDOM && g.CN < 6) return EWN_EUNSUPPORTED;
-    if (cfg->opponent_kind == EWN_OPP_MCTS && (cfg->num_simulations < 1 || cfg->num_env_copies < 1)) return EWN_EINVAL;
-    u32 W = cfg->mt_window ? cfg->mt_window : 128u;
-    if (W < 16 || W > EWN_MT_WINDOW_MAX) return EWN_EINVAL;
-    k.N = cfg->n_lanes; k.opp = cfg->opponent_kind; k.depth = cfg->max_depth; k.heur = cfg->heuristic;
-    k.rng_kind = cfg->rng_kind; k.shaped = cfg->shaped; k.autoreset = cfg->autoreset; k.refresh = cfg->shaped_refresh_on_reset;
-    k.lane_offset = cfg->lane_offset; k.nsim_total = cfg->num_simulations * cfg->num_env_copies;
-    k.seed_stride = cfg->seed_stride; k.W = W;
-    k.rng_words = EWN_RNG_HDR + (cfg->rng_kind == EWN_RNG_MT19937 ? 3u * W + 1u : 0u);
-    k.reward = cfg->reward; k.illegal_reward = cfg->illegal_move_reward; k.key = cfg->philox_key;
-    return EWN_OK;
-}
-
-static int launch_status()
-{
-    return hipGetLastError() == hipSuccess ? EWN_OK : EWN_ELAUNCH;
-}
-
-// specialised depth-3 tables exist for cube_layer 3 and board sizes whose distinct leaf values fit 10-bit ranks
-static int64_t fast_tables_bytes(int S, int L)
-{
-    if (L != 3) return 0;
-    switch (S) {
-    case 5: return (int64_t)FAST_TAB_BYTES(5);
-    case 6: return (int64_t)FAST_TAB_BYTES(6);
-    case 7: return (int64_t)FAST_TAB_BYTES(7);
-    case 8: return (int64_t)FAST_TAB_BYTES(8);
-    default: return 0;
-    }
-}
-
-// Lanes of one wavefront that share a game in k_step_d3: enough to put several waves on every SIMD
-// (1024 SIMDs x 64 lanes) at the given number of games.  EWN_D3_T=0 disables the kernel, 1/2/4 forces T.
-static int d3_threads_per_game(int n_games)
-{
-    static const int forced = [] { const char *e = getenv("EWN_D3_T"); return e ? atoi(e) : -1; }();
-    if (forced == 0 || forced == 1 || forced == 2 || forced == 4) return forced;
-    // measured on MI355X (tools/sweep_T.sh, us per step, T = 1 / 2 / 4): 16 384 games 14.9 / 10.9 / 10.0; 32 768: 15.1 / 11.3 / 12.6;
-    // 65 536: 15.8 / 14.8 / 18.7; 131 072: 21.6 / 22.4 / 32.3; 262 144: 36.3 / 39.4 / 57.5; 1 048 576: 118 / 132 / 205.
-    // The kernel is bound by integer VALU issue once the chip is full, so lanes added beyond what hides the LDS/global
-    // latency only add redundant instructions.
-    if (n_games >= 131072) return 1;
-    if (n_games >= 32768) return 2;
-    return 4;
-}
-
 #define GRID(n) dim3((unsigned)(((long long)(n) + BS - 1) / BS))
 #define BY_NW(g, expr1, expr2) do { if ((g).CN <= 10) { expr1; } else { expr2; } } while (0)
 
@@ -831,21 +667,6 @@ int ewn_rng_words(const ewn_config *cfg)
     Geom g; KCfg k;
     const int rc = check_cfg(cfg, g, k);
     return rc ? rc : (int)k.rng_words;
-}
-
-// the lean kernel's MT refill hand-off (ewn_core.hpp MtQueue): ctrl[4] | cnt[2][nb4] | list[2][nblk][2 * games per block] x 16 B.
-// The layout depends on the lanes-per-game T the launch picks (games per block = 256 / T, nblk = ceil(N / games per block)), and
-// the rounding-up of nblk makes T = 1 the LARGEST for a small N (64 lanes: one block of 512 slots), so take the maximum over T.
-// (Sizing it for T = 4 only let a T = 1 launch on 64 lanes write 8 KB past the buffer -- into whatever tensor came next.)
-static int64_t mtq_bytes(int64_t N)
-{
-    int64_t best = 0;
-    for (int T = 1; T <= 4; T *= 2) {
-        const int64_t gpb = D3_BS / T, nblk = (N + gpb - 1) / gpb, nb4 = (nblk + 3) / 4 * 4;
-        const int64_t b = 16 + 2 * nb4 * 4 + 2 * nblk * (2 * gpb) * 16;
-        if (b > best) best = b;
-    }
-    return best;
 }
 
 int64_t ewn_step_scratch_bytes(const ewn_config *cfg)
@@ -940,7 +761,6 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
     KScratch sc = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     // MT kind with auto-reset: the step kernel flags the lanes whose spare window it consumed; k_mt_refill rebuilds them right after
     const bool refill = cfg->rng_kind == EWN_RNG_MT19937 && cfg->autoreset;
-    bool lean_fused_refill = false;
     if (cfg->opponent_kind == EWN_OPP_MCTS) {
         if (!scratch) return EWN_ENULL;
         carve_scratch(g, k, scratch, sc);
@@ -952,37 +772,11 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
         const bool lean_random = st->tables && fast_tables_bytes(g.S, g.L) > 0 && cfg->opponent_kind == EWN_OPP_RANDOM;
         if (fast && (cfg->max_depth == 4 || cfg->max_depth == 6)) ks.tables = (const int8_t *)st->tables + fast_tables_bytes(g.S, g.L); // the max_depth-4 image
         if ((fast || lean_random) && !cfg->shaped && d3_threads_per_game(k.N) > 0) {
-            // the lean fused kernel: canonical ring space end to end, T lanes per game (ewn_step_d3.hpp)
-            // leaves are shared among lanes at depth 3-4; depth 5-6 splits its inner dice over two lanes while the chip is not full
-            const int T = (lean_random || cfg->max_depth < 3) ? 1 : (cfg->max_depth > 4 ? (k.N <= 131072 && d3_threads_per_game(k.N) != 1 ? 2 : 1) : d3_threads_per_game(k.N));
-            const int gpb0 = D3_BS / T, step_blocks = (k.N + gpb0 - 1) / gpb0;
-            // MT kind with auto-reset: window refills are extra blocks of the same launch (needs the caller's scratch)
+            // the lean fused kernel: canonical ring space end to end, T lanes per game (ewn_step_d3.hpp / ewn_step_d3.hip).
+            // MT kind with auto-reset: window refills are extra blocks of the same launch (needs the caller's scratch).
             const bool fused_refill = refill && scratch != nullptr;
-            lean_fused_refill = fused_refill;
-            // one refill block (one wave) per step block: a lane of it rebuilds at most one window, ~29 k cycles, well inside the
-            // step role's ~45 k.  Measured at 65 536 lanes: 256 refill blocks (two regions each, two chains back to back) 38.4 us
-            // per launch, 512 blocks 26.5 us.
-            const int refill_blocks = fused_refill ? step_blocks : 0;
-            D3Cfg dc = { k.N, k.rng_kind, k.autoreset, k.lane_offset, k.depth, refill_blocks, k.seed_stride, k.W, k.reward, k.key };
-            D3Buf db = { st->board, st->dice, st->done, st->rng, ks.tables, actions, out->reward, out->terminated,
-                         out->truncated, out->info, out->terminal_board, out->terminal_dice, out->random_action,
-                         fused_refill ? scratch : nullptr };
-            const int gpb = gpb0;
-            const dim3 grid((unsigned)(step_blocks + refill_blocks));
-            // LDS: boards + terminal boards | tables | decode scatter area | (MT) this block's parked refill requests; a refill block needs (W+1) x 65 words
-            size_t l3 = (((size_t)2 * gpb * g.cells + 15) & ~(size_t)15) + (size_t)gpb * 16; // + d3_decode's 16 bytes per game
-            if (fused_refill) l3 += 16 + (size_t)2 * gpb * 16;
-            const size_t need_refill = fused_refill ? (size_t)(k.W + 1) * 65 * 4 : 0;
-#define D3_LDS(SS) (l3 + FAST_TAB_BYTES(SS) > need_refill ? l3 + FAST_TAB_BYTES(SS) : need_refill)
-#define D3_LAUNCH(SS, TT, OO) do { if (k.rng_kind == 0) k_step_d3<SS, TT, OO, 0><<<grid, D3_BS, D3_LDS(SS), s>>>(dc, db); \
-                                   else k_step_d3<SS, TT, OO, 1><<<grid, D3_BS, D3_LDS(SS), s>>>(dc, db); } while (0)
-#define D3_BY_T(SS) do { if (lean_random) D3_LAUNCH(SS, 1, 1); else if (cfg->max_depth > 4) { if (T == 2) D3_LAUNCH(SS, 2, 2); else D3_LAUNCH(SS, 1, 2); } else if (T == 1) D3_LAUNCH(SS, 1, 0); else if (T == 2) D3_LAUNCH(SS, 2, 0); else D3_LAUNCH(SS, 4, 0); } while (0)
-            switch (g.S) {
-            case 5: D3_BY_T(5); break;
-            case 6: D3_BY_T(6); break;
-            case 7: D3_BY_T(7); break;
-            default: D3_BY_T(8); break;
-            }
+            rc = ewn_launch_step_d3(cfg, g, k, st, ks.tables, actions, out, scratch, lean_random, fused_refill, s);
+            if (rc || fused_refill) return rc;
         } else if (fast) {
             const size_t base = (lds + 15) & ~(size_t)15;
             switch (g.S) {
@@ -1007,14 +801,82 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
     }
     rc = launch_status();
     if (rc) return rc;
-    if (lean_fused_refill) {
-        k_mtq_flip<<<1, 64, 0, s>>>((u32 *)scratch);
-        rc = launch_status();
-    } else if (refill) {
+    if (refill) {
         k_mt_refill<<<dim3((unsigned)((k.N + REFILL_BS - 1) / REFILL_BS)), REFILL_BS, (size_t)(k.W + 1) * 65 * 4, s>>>(st->rng, k.N, k.W, k.seed_stride);
         rc = launch_status();
     }
     return rc;
+}
+
+// table image of a 'hybrid' search of the given max_depth: max_depth 4 and 6 read the second image (leaves averaged over six dice)
+static const void *fast_image(const void *tables, int S, int L, int max_depth)
+{
+    return (max_depth == 4 || max_depth == 6) ? (const void *)((const int8_t *)tables + fast_tables_bytes(S, L)) : tables;
+}
+
+// which k_rollout_d3 instantiation serves (cfg, agent): EWN_OK and the template selectors, or why not
+static int rollout_plan(const ewn_config *cfg, const Geom &g, const KCfg &k, int agent_kind, int agent_max_depth, int &T, int &opp, int &agent)
+{
+    if (fast_tables_bytes(g.S, g.L) <= 0 || cfg->shaped) return EWN_EUNSUPPORTED;
+    if (cfg->opponent_kind == EWN_OPP_RANDOM) opp = 1;
+    else if (cfg->opponent_kind == EWN_OPP_MINIMAX && cfg->heuristic == EWN_H_HYBRID) opp = cfg->max_depth > 4 ? 2 : 0;
+    else return EWN_EUNSUPPORTED;
+    if (agent_kind == EWN_AGENT_RANDOM) agent = 0;
+    else if (agent_kind == EWN_AGENT_MINIMAX) {
+        if (agent_max_depth < 1) return EWN_EINVAL;
+        if (agent_max_depth > EWN_MAX_DEPTH) return EWN_EUNSUPPORTED;
+        agent = agent_max_depth > 4 ? 2 : 1;
+    } else return EWN_EINVAL;
+    // the MT19937-compat windows of an auto-resetting lane are rebuilt BETWEEN launches (ewn_core.hpp): a launch that plays
+    // several episodes of a lane cannot use them.  Without auto-reset (one episode per lane: evaluation) the kind is fine.
+    if (cfg->rng_kind == EWN_RNG_MT19937 && cfg->autoreset) return EWN_EUNSUPPORTED;
+    const bool mt = cfg->rng_kind == EWN_RNG_MT19937;
+    if (agent != 0) T = 2;
+    else if (opp == 1) T = 1;
+    else if (opp == 2) T = mt ? 2 : (k.N <= 131072 ? 2 : 1);
+    else T = mt ? 1 : rollout_threads_per_game(k.N);
+    return EWN_OK;
+}
+
+int ewn_step_k_supported(const ewn_config *cfg, int agent_kind, int agent_max_depth)
+{
+    Geom g; KCfg k;
+    int rc = check_cfg(cfg, g, k);
+    if (rc) return rc;
+    int T, opp, agent;
+    rc = rollout_plan(cfg, g, k, agent_kind, agent_max_depth, T, opp, agent);
+    return rc == EWN_OK ? 1 : (rc == EWN_EUNSUPPORTED ? 0 : rc);
+}
+
+int ewn_step_k(const ewn_config *cfg, const ewn_state *st, int K, int agent_kind, int agent_max_depth, const ewn_rollout_out *out,
+               void *stream)
+{
+    Geom g; KCfg k;
+    int rc = check_cfg(cfg, g, k);
+    if (rc) return rc;
+    if (K < 1) return EWN_EINVAL;
+    if (!st || !st->board || !st->dice || !st->done || !st->rng || !st->tables) return EWN_ENULL;
+    int T, opp, agent;
+    rc = rollout_plan(cfg, g, k, agent_kind, agent_max_depth, T, opp, agent);
+    if (rc) return rc;
+    RollCfg rcf = { k.N, k.autoreset, k.lane_offset, k.depth, agent_max_depth, K, k.seed_stride, k.W, k.reward, k.key };
+    RollBuf rb;
+    memset(&rb, 0, sizeof(rb));
+    rb.board = st->board; rb.dice = st->dice; rb.done = st->done; rb.rng = st->rng;
+    rb.tables = opp == 1 ? st->tables : fast_image(st->tables, g.S, g.L, cfg->max_depth);
+    rb.agent_tables = agent == 0 ? rb.tables : fast_image(st->tables, g.S, g.L, agent_max_depth);
+    if (out) {
+        rb.t_board = out->board; rb.t_dice = out->dice; rb.t_action = out->action; rb.t_reward = out->reward;
+        rb.t_term = out->terminated; rb.t_trunc = out->truncated; rb.t_info = out->info;
+        rb.ret_sum = out->return_sum; rb.n_steps = out->n_steps; rb.n_episodes = out->n_episodes; rb.n_wins = out->n_wins;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    switch (g.S) {
+    case 5: return ewn_launch_rollout_s5(rcf, rb, T, opp, k.rng_kind, agent, s);
+    case 6: return ewn_launch_rollout_s6(rcf, rb, T, opp, k.rng_kind, agent, s);
+    case 7: return ewn_launch_rollout_s7(rcf, rb, T, opp, k.rng_kind, agent, s);
+    default: return ewn_launch_rollout_s8(rcf, rb, T, opp, k.rng_kind, agent, s);
+    }
 }
 
 static int query_geom(int S, int L, int M, const void *boards, Geom &g)

@@ -1,0 +1,205 @@
+// ewn_rollout.hpp -- K env steps in ONE launch (C ABI: ewn_step_k), for the case where the agent is an engine policy too:
+// the loop  `while not done: action, _ = agent.predict(obs); obs, reward, done, trunc, info = env.step(action)`  of the
+// reference's evaluation scripts (eval_minimax.py:16-50, eval_pairs.py:10-35) and of a rollout collector, with
+// agent in {RandomAgent, ExpectiMinimaxAgent('hybrid')}.
+//
+// Why a second kernel next to k_step_d3 (ewn_step_d3.hpp), measured there with in-kernel stamps at 65 536 lanes: of the
+// ~26 k cycles a wave spends per step, ~4.7 k are loading the state, staging the boards through LDS and decoding them and
+// ~3.6 k encoding and storing them again, and every launch ends with a device-wide barrier (the next step cannot start before
+// the slowest block of this one has finished: ~8 k cycles of ramp and tail per launch).  Here a game is loaded ONCE, stays
+// in registers (two occupancy masks + twelve position bytes + the RNG header) for K steps, and is stored once; blocks run
+// their K steps without ever waiting for each other.  Every step's observation / action / reward / flags can still be
+// written (ewn_rollout_out, a [K][N] trajectory: what a trainer's rollout buffer holds), through the same LDS-staged
+// coalesced copies; they are write-only traffic, nothing is read back.
+//
+// Results are identical, step for step, to calling ewn_step K times with the agent's action fed back (tests:
+// tests/test_gpu_rollout.py, against ewn_step and against the CPU oracle).
+#pragma once
+#include "ewn_step_d3.hpp"
+
+struct RollCfg {
+    int N, autoreset, lane_offset, depth, agent_depth, K;  // depth / agent_depth: max_depth of the opponent's / the agent's search
+    u32 seed_stride, W;
+    double reward;
+    u64 key;
+};
+
+struct RollBuf {
+    int8_t *board; int8_t *dice; uint8_t *done; u32 *rng;
+    const void *tables;        // table image of the opponent's search (ewn_fast.hpp)
+    const void *agent_tables;  // table image of the agent's search; == tables when both use the same image (or the agent is random)
+    // trajectory [K][N]..., each may be NULL
+    int8_t *t_board; int8_t *t_dice; int8_t *t_action; double *t_reward; uint8_t *t_term; uint8_t *t_trunc; uint8_t *t_info;
+    // per-lane accumulators, each may be NULL
+    double *ret_sum; int32_t *n_steps; int32_t *n_episodes; int32_t *n_wins;
+};
+
+// The position seen from the other side: sides swapped, every square rotated by 180 degrees (opponent_action's
+// np.rot90(-board, 2), envs/ewn.py:289-296), so that the side to move is the table's TOP_LEFT mover again.
+template <int S>
+EWN_DEV RState<S> rs_flip(const FastTab<S> *Tb, const RState<S> &s)
+{
+    typedef typename MaskOf<S>::type M;
+    RState<S> f;
+    u32 rp[6], rn[6];
+    #pragma unroll
+    for (int k = 0; k < 6; k++) { rp[k] = Tb->rot[pk_get(s.posN, k) & 63]; rn[k] = Tb->rot[pk_get(s.posP, k) & 63]; }
+    f.posP = PK_PADS; f.posN = PK_PADS; f.P = 0; f.N = 0;
+    #pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const bool ap = !(pk_get(s.posN, k) & PK_OFF), an = !(pk_get(s.posP, k) & PK_OFF);
+        f.posP |= (u64)(ap ? rp[k] : (u32)PK_OFF) << (8 * k);
+        f.posN |= (u64)(an ? rn[k] : (u32)PK_OFF) << (8 * k);
+        f.P |= ap ? ((M)1 << rp[k]) : (M)0;
+        f.N |= an ? ((M)1 << rn[k]) : (M)0;
+    }
+    return f;
+}
+
+// AGENT 0: RandomAgent (the hash-driven uniform legal pick of ewn_step_out.random_action); 1: ExpectiMinimaxAgent of
+// max_depth 1-4 ('hybrid'); 2: of max_depth 5-6.  OPP as in k_step_d3: 0 minimax max_depth 1-4, 1 RandomAgent, 2 minimax 5-6.
+template <int S, int T, int OPP, int RNGK, int AGENT>
+__global__ __launch_bounds__(D3_BS) void k_rollout_d3(RollCfg c, RollBuf B)
+{
+    constexpr int CELLS = S * S, GPB = D3_BS / T; // games per block
+    constexpr int TS = T > 2 ? 2 : T;             // lanes per game the depth-5 search can use
+    extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+    int8_t *tb = lds + ((GPB * CELLS + 15) & ~15);
+    tables_to_lds<FAST_TAB_BYTES(S)>(tb, (const int8_t *)B.tables); // LDS-DMA, waited for at the barrier
+    const FastTab<S> *Tb = (const FastTab<S> *)tb;
+    const FastTab<S> *Ta = Tb;
+    int8_t *after = tb + FAST_TAB_BYTES(S);
+    if (AGENT != 0 && B.agent_tables != B.tables) { // a second image for the agent's search (other depth class)
+        tables_to_lds<FAST_TAB_BYTES(S)>(after, (const int8_t *)B.agent_tables);
+        Ta = (const FastTab<S> *)after;
+        after += FAST_TAB_BYTES(S);
+    }
+    uint8_t *garr = (uint8_t *)after;             // 16 bytes per game: d3_decode's scatter area
+
+    const int g0 = (int)blockIdx.x * GPB, ng = min(GPB, c.N - g0);
+    const int gl = threadIdx.x / T, sub = threadIdx.x % T, game = g0 + gl;
+    const bool live = game < c.N, writer = live && sub == 0;
+
+    uint4 hdr = make_uint4(0u, 0u, 0u, 0u);
+    int dice = 1;
+    bool frozen = true;
+    if (live) {
+        hdr = *rng_hdr_ptr(B.rng, game);
+        dice = B.dice[game];
+        frozen = B.done[game] != 0;
+    }
+    const bool frozen0 = frozen;
+    block_copy_in(lds, B.board + (size_t)g0 * CELLS, ng * CELLS);
+    LaneRng r; r.load(RNGK, hdr, rng_win_ptr(B.rng, c.N, c.W, live ? game : 0, RNGF_CUR(hdr.w)), c.W, c.key);
+    r.begin_kernel();
+    lds_dma_wait();
+    __syncthreads();
+    int8_t *mine = lds + gl * CELLS;
+    RState<S> s;
+    d3_decode<S, T>(live ? mine : lds, sub, garr + gl * 16, s);
+    const bool want_board = B.t_board != nullptr;
+    double ret_acc = 0.0;
+    int n_steps = 0, n_eps = 0, n_wins = 0;
+
+    #pragma unroll 1
+    for (int kstep = 0; kstep < c.K; kstep++) {
+        const bool active = live && !frozen;
+        double reward = 0.0;
+        int term = 0, trunc = 0, info = EWN_INFO_NONE;
+        if (live && frozen) term = 1; // a finished, un-reset game stays put (as in ewn_step)
+        // ---- the agent's action for the current observation (the agent is the canonical BOTTOM_RIGHT side)
+        int aflag = 0, adir = 0;
+        if constexpr (AGENT == 0) {
+            // RandomAgent.predict: the same draw ewn_step_out.random_action makes at the end of the previous step
+            const u32 e = pk_sel<S>(Tb, s.posN, dice), pp = pk_pair(s.posN, e);
+            const u32 okm = (u32)Tb->lgn[pp & 0xFFu] | ((u32)Tb->lgn[pp >> 8] << 3);
+            const int n = __popc(okm);
+            if (n > 0) {
+                const u32 w = agent_hash(r.seed, r.draws(), (u32)(c.lane_offset + game), c.key);
+                const int slot = Tb->nth[okm * 8u + __umulhi(w, (u32)n)];
+                aflag = slot < 3 ? (int)(e >> 15) : 0;
+                adir = slot < 3 ? slot : slot - 3;
+            }
+        } else {
+            // ExpectiMinimaxAgent.predict(canonical observation): the agent's own position IS canonical for it once flipped
+            const RState<S> f = rs_flip<S>(Ta, s);
+            if constexpr (AGENT == 1) d3_search<S, T>(Ta, f, dice, sub, c.agent_depth, aflag, adir);
+            else d5_search<S, TS>(Ta, f, dice, T > 2 ? (sub & 1) : sub, aflag, adir);
+        }
+        if (active) { // a frozen lane's stream stays where its last step left it
+            if constexpr (RNGK == 0) r.prefetch();
+            r.begin_step();
+            if constexpr (RNGK == 1) r.ps.prime();
+        }
+        bool reply = false;
+        if (active) {
+            // agent half, envs/ewn.py:438-458
+            const int k = pk_cube(pk_sel<S>(Tb, s.posN, dice), aflag == 1);
+            const int q = Tb->nbn[adir][pk_get(s.posN, k)]; // no cube at all: byte 6 -> 255
+            if (q == 255) { reward = -c.reward; term = 1; trunc = 1; info = EWN_INFO_INVALID_PLAYER; }
+            else {
+                rs_move<S, false>(s, k, q);
+                if (q == Tb->ri_origin || s.P == 0) { reward = c.reward; term = 1; info = EWN_INFO_WON; }
+                else { dice = r.randint(1, 7); reply = true; }
+            }
+        }
+        // the opponent's search: run by every lane (lanes without a pending reply compute on a harmless state)
+        int oflag = 0, odir = 0;
+        if constexpr (OPP == 0) d3_search<S, T>(Tb, s, dice, sub, c.depth, oflag, odir);
+        if constexpr (OPP == 2) d5_search<S, TS>(Tb, s, dice, T > 2 ? (sub & 1) : sub, oflag, odir);
+        if (reply) {
+            // opponent half, envs/ewn.py:464-486
+            const u32 e = pk_sel<S>(Tb, s.posP, dice);
+            if constexpr (OPP == 1) {
+                const u32 pp = pk_pair(s.posP, e);
+                const u32 okm = (u32)Tb->lgp[pp & 0xFFu] | ((u32)Tb->lgp[pp >> 8] << 3);
+                const int slot = Tb->nth[okm * 8u + (u32)r.randint(0, __popc(okm))]; // 0..5 = cube slot * 3 + dir
+                oflag = slot < 3 ? (int)(e >> 15) : 0;
+                odir = slot < 3 ? slot : slot - 3;
+            }
+            const int k = pk_cube(e, oflag == 1);
+            const int q = Tb->nbp[odir][pk_get(s.posP, k)];
+            rs_move<S, true>(s, k, q);
+            if (q == CELLS - 1 || s.N == 0) { reward = -c.reward; term = 1; info = EWN_INFO_LOST; }
+            else dice = r.randint(1, 7);
+        }
+        if (active) {
+            ret_acc += reward; n_steps++; n_eps += term; n_wins += info == EWN_INFO_WON ? 1 : 0;
+            if (term) {
+                if (c.autoreset) { // reset(seed = next_seed) + setup_game (envs/ewn.py:488-494, 94-108); Philox kind only (host check)
+                    r.next_episode(B.rng, c.N, game, c.seed_stride, c.key, nullptr);
+                    d3_init_state<S>(Tb, s);
+                    dice = r.first_dice(6);
+                } else frozen = true;
+            }
+        }
+        // ---- this step's row of the trajectory
+        if (writer) {
+            const size_t o = (size_t)kstep * c.N + game;
+            if (B.t_action) ((uint16_t *)B.t_action)[o] = (uint16_t)((uint8_t)aflag | ((uint16_t)(uint8_t)adir << 8));
+            if (B.t_dice) B.t_dice[o] = (int8_t)dice;
+            if (B.t_reward) B.t_reward[o] = reward;
+            if (B.t_term) B.t_term[o] = (uint8_t)term;
+            if (B.t_trunc) B.t_trunc[o] = (uint8_t)trunc;
+            if (B.t_info) B.t_info[o] = (uint8_t)info;
+        }
+        if (want_board) {
+            if (live) d3_encode<S, T>(Tb, s, sub, mine);
+            __syncthreads();
+            block_copy_out(B.t_board + ((size_t)kstep * c.N + g0) * CELLS, lds, ng * CELLS);
+            __syncthreads();
+        }
+    }
+    // ---- the state goes back to HBM once
+    if (live) d3_encode<S, T>(Tb, s, sub, mine);
+    if (writer) {
+        if (!frozen0) { *rng_hdr_ptr(B.rng, game) = r.header(); B.dice[game] = (int8_t)dice; }
+        B.done[game] = frozen ? 1 : 0;
+        if (B.ret_sum) B.ret_sum[game] += ret_acc;
+        if (B.n_steps) B.n_steps[game] += n_steps;
+        if (B.n_episodes) B.n_episodes[game] += n_eps;
+        if (B.n_wins) B.n_wins[game] += n_wins;
+    }
+    __syncthreads();
+    block_copy_out(B.board + (size_t)g0 * CELLS, lds, ng * CELLS);
+}

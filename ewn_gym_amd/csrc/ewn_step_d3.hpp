@@ -437,7 +437,9 @@ struct D3Buf {
     void *mtq; // MT kind with auto-reset: the refill hand-off area (scratch), else NULL
 };
 
+#ifndef D3_BS
 #define D3_BS 256
+#endif
 #ifndef D3_REFILL_PRIO
 #define D3_REFILL_PRIO 3
 #define D3_STEP_PRIO 0
@@ -520,7 +522,7 @@ EWN_DEV void d3_init_state(const FastTab<S> *Tb, RState<S> &s)
 // EinsteinWuerfeltNichtEnv.step (envs/ewn.py:436-486), minimax(depth 3, hybrid) opponent, cube_layer 3.
 // T lanes per game; lanes of a group run identical code on identical data except inside d3_search.
 // Between two fused MT launches: the list just produced becomes the one to consume.
-__global__ void k_mtq_flip(u32 *ctrl) { if (threadIdx.x == 0 && blockIdx.x == 0) ctrl[0] ^= 1u; }
+static __global__ void k_mtq_flip(u32 *ctrl) { if (threadIdx.x == 0 && blockIdx.x == 0) ctrl[0] ^= 1u; }
 
 // OPP 0: ExpectiMinimaxAgent(max_depth=3, 'hybrid') reply;  OPP 1: RandomAgent reply (classical_policies/random_policy.py:11-15)
 // RNGK: the dice RNG kind as a compile-time constant, so each instantiation carries only its own generator's registers

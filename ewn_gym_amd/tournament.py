@@ -47,15 +47,32 @@ def _policy(spec, cube_layer, key):
     raise ValueError("unknown agent kind %r" % kind)
 
 
-def evaluate(agent, opponent, num=1024, board_size=5, cube_layer=3, rng="mt19937", seed_offset=0, key=12345, max_steps=400):
+def evaluate(agent, opponent, num=1024, board_size=5, cube_layer=3, rng="mt19937", seed_offset=0, key=12345, max_steps=400,
+             use_rollout=True, chunk=16):
     """agent: a dict like the opponent's or a callable policy (board, dice, t) -> actions.
     agent / opponent: dicts {"kind": "random"|"minimax"|"mcts", max_depth=, heuristic=, num_simulations=, num_env_copies=}.
-    Returns per-episode scores (float64 tensor), episode lengths and summary statistics."""
+    Returns per-episode scores (float64 tensor), episode lengths and summary statistics.
+    When both sides are engine policies the table-driven kernels cover (RandomAgent, 'hybrid' minimax; cube_layer 3) the whole
+    predict/step loop runs on the device, `chunk` steps per launch (ewn_step_k); otherwise one policy kernel + one ewn_step per
+    step.  Both give identical per-episode results for deterministic agents ("engine" in the result says which one ran)."""
     env = VecEWN(num, board_size=board_size, cube_layer=cube_layer, opponent_policy=opponent["kind"],
                  max_depth=opponent.get("max_depth", 3), heuristic=opponent.get("heuristic", "hybrid"),
                  num_simulations=opponent.get("num_simulations", 10), num_env_copies=opponent.get("num_env_copies", 5),
                  rng=rng, autoreset=False, philox_key=key ^ 0x5DEECE66D)
     env.reset(seeds=torch.arange(seed_offset, seed_offset + num, dtype=torch.int64).to(torch.int32))
+    if (use_rollout and isinstance(agent, dict) and agent["kind"] in ("random", "minimax") and agent.get("heuristic", "hybrid") == "hybrid"
+            and env.supports_rollout(agent["kind"], agent.get("max_depth", 3))):
+        totals = env.alloc_totals()
+        for _ in range(0, max_steps, chunk):
+            env.rollout(chunk, agent=agent["kind"], agent_max_depth=agent.get("max_depth", 3), totals=totals)
+            if bool((env.done != 0).all()):
+                break
+        env.check_rng()
+        score, length = totals["return_sum"], totals["n_steps"]   # un-shaped env: the only non-zero reward of an episode is its last
+        wins = int((score > 0).sum().item())
+        lo, hi = wilson(wins, num)
+        return {"scores": score, "lengths": length, "wins": wins, "episodes": num, "win_rate": wins / num, "engine": "ewn_step_k",
+                "ci95": [lo, hi], "avg_score": float(score.mean().item()), "avg_length": float(length.float().mean().item())}
     policy = _policy(agent, cube_layer, key)
     score = torch.zeros(num, dtype=torch.float64, device=env.device)
     length = torch.zeros(num, dtype=torch.int32, device=env.device)
@@ -71,7 +88,7 @@ def evaluate(agent, opponent, num=1024, board_size=5, cube_layer=3, rng="mt19937
     env.check_rng()
     wins = int((score > 0).sum().item())
     lo, hi = wilson(wins, num)
-    return {"scores": score, "lengths": length, "wins": wins, "episodes": num, "win_rate": wins / num,
+    return {"scores": score, "lengths": length, "wins": wins, "episodes": num, "win_rate": wins / num, "engine": "ewn_step",
             "ci95": [lo, hi], "avg_score": float(score.mean().item()), "avg_length": float(length.float().mean().item())}
 
 

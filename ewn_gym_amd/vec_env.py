@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import HEUR, OPP, RNG, EwnConfig, EwnState, EwnStepOut, check
+from ._lib import AGENT, HEUR, OPP, RNG, EwnConfig, EwnRolloutOut, EwnState, EwnStepOut, check
 
 
 def _require_gpu(device):
@@ -141,9 +141,45 @@ class VecEWN:
             raise _lib.EwnError("MT19937-compat dice stream exhausted (>= 454 draws in one episode) on lanes %s: results are no "
                                 "longer bit-identical to numpy's stream; use rng='philox' for such long games" % lanes)
 
-    def supports_rollout(self):
-        """True when ewn_step_k (K env steps per launch, in-engine agent) exists for this configuration"""
-        return False
+    # -- K env steps per launch with an in-engine agent (ewn_step_k; eval_minimax.py:16-50's loop on the device)
+    def supports_rollout(self, agent="random", agent_max_depth=3):
+        """True when ewn_step_k exists for this configuration and agent"""
+        if self.tables is None or agent not in AGENT:
+            return False
+        return self.lib.ewn_step_k_supported(C.byref(self.cfg), AGENT[agent], int(agent_max_depth)) == 1
+
+    def alloc_rollout(self, K, board=True):
+        """Trajectory buffers for rollout(K, traj=...): dict of [K, N, ...] tensors (the observation column is optional)"""
+        dev, N, S = self.device, self.N, self.S
+        t = {"dice": torch.zeros((K, N), dtype=torch.int8, device=dev),
+             "action": torch.zeros((K, N, 2), dtype=torch.int8, device=dev),
+             "reward": torch.zeros((K, N), dtype=torch.float64, device=dev),
+             "terminated": torch.zeros((K, N), dtype=torch.uint8, device=dev),
+             "truncated": torch.zeros((K, N), dtype=torch.uint8, device=dev),
+             "info": torch.zeros((K, N), dtype=torch.uint8, device=dev)}
+        if board:
+            t["board"] = torch.zeros((K, N, S, S), dtype=torch.int8, device=dev)
+        return t
+
+    def alloc_totals(self):
+        """Per-lane accumulators for rollout(..., totals=...): return_sum, n_steps, n_episodes, n_wins (rollout ADDS to them)"""
+        dev, N = self.device, self.N
+        return {"return_sum": torch.zeros(N, dtype=torch.float64, device=dev), "n_steps": torch.zeros(N, dtype=torch.int32, device=dev),
+                "n_episodes": torch.zeros(N, dtype=torch.int32, device=dev), "n_wins": torch.zeros(N, dtype=torch.int32, device=dev)}
+
+    def rollout(self, K, agent="random", agent_max_depth=3, traj=None, totals=None):
+        """Play K steps of every lane in one launch, the agent being RandomAgent or ExpectiMinimaxAgent(agent_max_depth).
+        traj: dict from alloc_rollout (first dimension >= K) or None; totals: dict from alloc_totals or None."""
+        traj, totals = traj or {}, totals or {}
+        for v in traj.values():
+            assert v.shape[0] >= K and v.shape[1] == self.N
+        out = EwnRolloutOut(_ptr(traj.get("board")), _ptr(traj.get("dice")), _ptr(traj.get("action")), _ptr(traj.get("reward")),
+                            _ptr(traj.get("terminated")), _ptr(traj.get("truncated")), _ptr(traj.get("info")),
+                            _ptr(totals.get("return_sum")), _ptr(totals.get("n_steps")), _ptr(totals.get("n_episodes")),
+                            _ptr(totals.get("n_wins")))
+        check(self.lib.ewn_step_k(C.byref(self.cfg), C.byref(self._st), int(K), AGENT[agent], int(agent_max_depth), C.byref(out),
+                                  _stream()), "ewn_step_k")
+        return self.board, self.dice
 
     def set_obs(self, boards, dice):
         """Overwrite the observation of every lane (agent = TOP_LEFT to move); RNG state is kept."""

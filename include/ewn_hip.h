@@ -163,6 +163,39 @@ int ewn_reset(const ewn_config *cfg, const ewn_state *st, const uint32_t *seeds,
 int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, const ewn_step_out *out,
              void *scratch, void *stream);
 
+/* ---- K env steps per launch, the agent played by the engine too --------------------------------------------------
+ * Replaces the evaluation loop of eval_minimax.py:16-50 / eval_pairs.py:10-35
+ *     while not done: action, _ = agent.predict(obs); obs, reward, done, trunc, info = env.step(action)
+ * (and a rollout collector's inner loop) when `agent` is one of the classical policies: the state is read once, stays in
+ * registers for K steps and is written once; results are identical, step for step, to K ewn_step calls with the agent's
+ * action fed back.  Available for the table-driven configurations (cube_layer 3, board sizes 5..8, ewn_state.tables set,
+ * un-shaped, opponent RandomAgent or 'hybrid' minimax); MT19937-compat dice only without auto-reset. */
+#define EWN_AGENT_RANDOM 0  /* RandomAgent.predict (classical_policies/random_policy.py:11-15): the hash-driven uniform legal pick
+                               of ewn_step_out.random_action, same stream */
+#define EWN_AGENT_MINIMAX 1 /* ExpectiMinimaxAgent(agent_max_depth, 'hybrid').predict (classical_policies/minimax.py:89-93) */
+
+typedef struct ewn_rollout_out {
+    /* trajectory, row k = step k of this call; every pointer may be NULL (that column is not written) */
+    int8_t *board;       /* [K][N][S*S] observation after step k (after the auto-reset, like ewn_state.board after ewn_step) */
+    int8_t *dice;        /* [K][N] */
+    int8_t *action;      /* [K][N][2] the action the agent played at step k */
+    double *reward;      /* [K][N] */
+    uint8_t *terminated; /* [K][N] */
+    uint8_t *truncated;  /* [K][N] */
+    uint8_t *info;       /* [K][N] EWN_INFO_* */
+    /* per-lane totals over the K steps, ADDED to what the buffers hold; every pointer may be NULL */
+    double *return_sum;  /* [N] sum of rewards */
+    int32_t *n_steps;    /* [N] steps played (a finished, un-reset lane plays none) */
+    int32_t *n_episodes; /* [N] episodes finished */
+    int32_t *n_wins;     /* [N] of which won ("You won!", envs/ewn.py:454) */
+} ewn_rollout_out;
+
+/* 1 if ewn_step_k serves this configuration and agent, 0 if not, < 0 on an invalid configuration */
+int ewn_step_k_supported(const ewn_config *cfg, int agent_kind, int agent_max_depth);
+/* K >= 1 steps of every lane; out may be NULL (only the state advances).  No scratch; one kernel launch. */
+int ewn_step_k(const ewn_config *cfg, const ewn_state *st, int K, int agent_kind, int agent_max_depth,
+               const ewn_rollout_out *out, void *stream);
+
 /* ---- stateless policy / rule queries on M given observations (canonical: TOP_LEFT to move) ---- */
 
 /* get_legal_actions (envs/ewn.py:338-375), find_cube_to_move (:178-215), check_win (:131-142).

@@ -34,6 +34,28 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     assert C.sizeof(EwnConfig) == 14 * 4 + 2 * 4 + 2 * 8 + 8
     assert C.sizeof(_lib.EwnState) == 7 * 8 and C.sizeof(_lib.EwnStepOut) == 7 * 8
+    assert C.sizeof(_lib.EwnRolloutOut) == 11 * 8
+
+
+def test_step_k_availability_is_decided_on_the_host():
+    """ewn_step_k: table-driven configurations only; MT19937-compat dice only without auto-reset (its windows are rebuilt
+    between launches); unknown agents are invalid, unsupported ones answer 0."""
+    lib = _lib.load()
+    ok = lambda **kw: lib.ewn_step_k_supported(C.byref(cfg(**kw)), kw.pop("_agent", 0), kw.pop("_depth", 3))  # noqa: E731
+    assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=1, rng_kind=1, autoreset=1)), 0, 0) == 1
+    assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=1, rng_kind=0, autoreset=1)), 0, 0) == 0
+    assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=1, rng_kind=0, autoreset=0)), 1, 5) == 1
+    assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=0, rng_kind=1)), 1, 3) == 1
+    assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=2, rng_kind=1)), 0, 0) == 0          # MCTS opponent: split-phase step only
+    assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=1, rng_kind=1, shaped=1)), 0, 0) in (0, 1)
+    assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=1, rng_kind=1, board_size=7, cube_layer=4)), 0, 0) == 0
+    assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=1, rng_kind=1)), 1, 7) == 0
+    assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=1, rng_kind=1)), 1, 0) == -1
+    assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=1, rng_kind=1)), 9, 3) == -1
+    assert lib.ewn_step_k_supported(C.byref(cfg(n_lanes=0)), 0, 0) == -1
+    st = _lib.EwnState()
+    assert lib.ewn_step_k(C.byref(cfg(rng_kind=1)), C.byref(st), 4, 0, 0, None, None) == -2
+    assert lib.ewn_step_k(C.byref(cfg(rng_kind=1)), C.byref(st), 0, 0, 0, None, None) == -1
 
 
 def test_config_validation_on_host():

@@ -37,7 +37,7 @@ def _slice_lockstep(ea, N, lo, hi, steps, raw_every=0, **kw):
     """N lanes on the GPU, lanes [lo, hi) followed by the oracle (same seeds, global lane ids, actions)."""
     okw = dict(kw)
     opp = okw.pop("opponent_policy")
-    env = ea.VecEWN(N, opponent_policy=opp, autoreset=True, seed_stride=N, **kw)
+    env = ea.VecEWN(N, opponent_policy=opp, autoreset=True, seed_stride=N, **okw)
     seeds = (np.arange(N, dtype=np.uint64) * 13 + 9487).astype(np.uint32)
     env.reset(seeds=seeds)
     orc = po.OracleVecEnv(hi - lo, opponent=opp, autoreset=True, seed_stride=N, lane_offset=lo, **okw)

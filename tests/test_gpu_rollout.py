@@ -1,0 +1,169 @@
+"""ewn_step_k (K env steps per launch, the agent played by the engine) against the CPU oracle, step for step:
+every column of the trajectory, the carried-over state between launches, the per-lane totals -- bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import pyoracle as po  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ea():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import ewn_gym_amd
+    return ewn_gym_amd
+
+
+def bits(x):
+    return np.ascontiguousarray(x, dtype=np.float64).view(np.uint64)
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
+
+
+def _rollout_vs_oracle(ea, N, lo, hi, K, launches, agent="random", agent_max_depth=3, autoreset=True, board_column=True, **kw):
+    okw = dict(kw)
+    opp = okw.pop("opponent_policy")
+    env = ea.VecEWN(N, opponent_policy=opp, autoreset=autoreset, seed_stride=N, **okw)
+    assert env.supports_rollout(agent, agent_max_depth)
+    seeds = (np.arange(N, dtype=np.uint64) * 7 + 1234).astype(np.uint32)
+    env.reset(seeds=seeds)
+    S, L = kw.get("board_size", 5), 3
+    orc = po.OracleVecEnv(hi - lo, opponent=opp, autoreset=autoreset, seed_stride=N, lane_offset=lo, **okw)
+    ob, od = orc.reset(seeds=seeds[lo:hi])
+    traj = env.alloc_rollout(K, board=board_column)
+    totals = env.alloc_totals()
+    frozen = np.zeros(hi - lo, bool)
+    ret = np.zeros(hi - lo)
+    nst = np.zeros(hi - lo, np.int64)
+    nep = np.zeros(hi - lo, np.int64)
+    nwin = np.zeros(hi - lo, np.int64)
+    for launch in range(launches):
+        env.rollout(K, agent=agent, agent_max_depth=agent_max_depth, traj=traj, totals=totals)
+        tj = {k: cpu(v[:, lo:hi]) for k, v in traj.items()}
+        for k in range(K):
+            if agent == "random":
+                acts = orc.random_actions()
+            else:
+                acts = po.predict_minimax(ob, od, agent_max_depth, "hybrid", cube_layer=L)[0]
+            live = ~frozen
+            ctx = (kw, launch, k)
+            assert np.array_equal(tj["action"][k][live], acts[live]), ctx
+            ob, od, r, te, tr, info = orc.step(np.where(live[:, None], acts, 0).astype(np.int8))
+            if board_column:
+                assert np.array_equal(tj["board"][k], ob), ctx
+            assert np.array_equal(tj["dice"][k], od), ctx
+            assert np.array_equal(bits(tj["reward"][k]), bits(r)), ctx
+            assert np.array_equal(tj["terminated"][k], te) and np.array_equal(tj["truncated"][k], tr), ctx
+            assert np.array_equal(tj["info"][k], info), ctx
+            ret += np.where(live, r, 0.0)
+            nst += live
+            nep += live & (te != 0)
+            nwin += live & (info == 2)
+            if not autoreset:
+                frozen |= te != 0
+        # the state written back at the end of the launch is the oracle's
+        assert np.array_equal(cpu(env.board[lo:hi]), ob) and np.array_equal(cpu(env.dice[lo:hi]), od), (kw, launch)
+        assert np.array_equal(cpu(env.done[lo:hi]) != 0, frozen), (kw, launch)
+    assert np.array_equal(bits(cpu(totals["return_sum"][lo:hi])), bits(ret))
+    assert np.array_equal(cpu(totals["n_steps"][lo:hi]), nst) and np.array_equal(cpu(totals["n_episodes"][lo:hi]), nep)
+    assert np.array_equal(cpu(totals["n_wins"][lo:hi]), nwin)
+    return int(nep.sum())
+
+
+@pytest.mark.parametrize("N,lo", [(1500, 0), (40000, 30000), (140000, 131000)])   # 4, 2 and 1 lanes per game
+def test_rollout_random_agent_depth3_opponent(ea, N, lo):
+    n = _rollout_vs_oracle(ea, N, lo, lo + 384, 9, 3, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=2024)
+    assert n > 384     # every lane of the slice went through auto-resets inside the launches
+
+
+@pytest.mark.parametrize("depth", [1, 2, 4])
+def test_rollout_other_table_depths(ea, depth):
+    _rollout_vs_oracle(ea, 700, 100, 500, 6, 2, opponent_policy="minimax", max_depth=depth, rng="philox", philox_key=depth)
+
+
+def test_rollout_depth5_opponent(ea):
+    _rollout_vs_oracle(ea, 200, 0, 96, 5, 2, opponent_policy="minimax", max_depth=5, rng="philox", philox_key=55)
+
+
+@pytest.mark.parametrize("S", [6, 7, 8])
+def test_rollout_other_board_sizes(ea, S):
+    _rollout_vs_oracle(ea, 1000, 300, 600, 8, 2, board_size=S, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=S)
+    _rollout_vs_oracle(ea, 40000, 20000, 20128, 5, 2, board_size=S, opponent_policy="random", rng="philox", philox_key=S + 1, board_column=False)
+
+
+def test_rollout_random_opponent_and_mt19937_without_autoreset(ea):
+    _rollout_vs_oracle(ea, 3000, 1000, 1600, 10, 3, opponent_policy="random", rng="philox", philox_key=3)
+    # numpy-compatible dice, one episode per lane (the evaluation scripts' shape): lanes freeze as they finish
+    _rollout_vs_oracle(ea, 1024, 0, 512, 8, 4, autoreset=False, opponent_policy="random", rng="mt19937")
+    _rollout_vs_oracle(ea, 1024, 0, 512, 8, 3, autoreset=False, opponent_policy="minimax", max_depth=3, rng="mt19937")
+    _rollout_vs_oracle(ea, 256, 0, 128, 6, 3, autoreset=False, opponent_policy="minimax", max_depth=5, rng="mt19937")
+
+
+@pytest.mark.parametrize("agent_depth,opp,opp_depth,rng", [(3, "minimax", 3, "mt19937"), (2, "random", 3, "philox"), (4, "minimax", 3, "philox"),
+                                                          (3, "minimax", 4, "mt19937"), (5, "minimax", 3, "mt19937"), (3, "minimax", 5, "philox"),
+                                                          (5, "random", 3, "mt19937")])
+def test_rollout_minimax_agent(ea, agent_depth, opp, opp_depth, rng):
+    """ExpectiMinimaxAgent as the agent (eval_minimax.py's loop on the device): the agent's search runs on the flipped position;
+    depth classes 1-4 and 5-6 on either side, same or different table images."""
+    n = 160 if max(agent_depth, opp_depth) >= 5 else 512
+    _rollout_vs_oracle(ea, n, 0, min(n, 256), 6, 3, agent="minimax", agent_max_depth=agent_depth, autoreset=False,
+                       opponent_policy=opp, max_depth=opp_depth, rng=rng, philox_key=agent_depth * 10 + opp_depth)
+
+
+def test_rollout_minimax_agent_with_autoreset_on_7x7(ea):
+    _rollout_vs_oracle(ea, 300, 0, 200, 7, 2, agent="minimax", agent_max_depth=3, board_size=7, opponent_policy="minimax", max_depth=2,
+                       rng="philox", philox_key=77)
+
+
+def test_rollout_equals_the_step_loop_at_full_size(ea):
+    """65 536 lanes: K steps in one launch == K ewn_step launches with the fused RandomAgent action fed back (state, RNG headers
+    and every step's outputs); the first action of the loop is the oracle-checked hash pick taken from a 1-step rollout."""
+    N, K = 65536, 12
+    kw = dict(opponent_policy="minimax", max_depth=3, rng="philox", philox_key=2024, autoreset=True, seed_stride=N)
+    seeds = (np.arange(N, dtype=np.uint64) + 9487).astype(np.uint32)
+    a = ea.VecEWN(N, **kw)
+    b = ea.VecEWN(N, want_random_action=True, **kw)
+    a.reset(seeds=seeds)
+    b.reset(seeds=seeds)
+    traj = a.alloc_rollout(K)
+    a.rollout(K, traj=traj)
+    acts = traj["action"][0].clone()          # what RandomAgent played at step 0
+    buf = b.random_action
+    buf.copy_(acts)
+    for k in range(K):
+        assert torch.equal(traj["action"][k], buf)
+        bo, di, r, te, tr, info = b.step(buf)
+        assert torch.equal(traj["board"][k], bo) and torch.equal(traj["dice"][k], di), k
+        assert torch.equal(traj["reward"][k], r) and torch.equal(traj["terminated"][k], te) and torch.equal(traj["info"][k], info), k
+    assert torch.equal(a.board, b.board) and torch.equal(a.dice, b.dice) and torch.equal(a.rng_state, b.rng_state)
+    # shard invariance: two half-size engines with global lane ids give the same trajectory
+    h0 = ea.VecEWN(N // 2, lane_offset=0, **kw)
+    h1 = ea.VecEWN(N // 2, lane_offset=N // 2, **kw)
+    h0.reset(seeds=seeds[:N // 2])
+    h1.reset(seeds=seeds[N // 2:])
+    t0, t1 = h0.alloc_rollout(K), h1.alloc_rollout(K)
+    h0.rollout(K, traj=t0)
+    h1.rollout(K, traj=t1)
+    for key in traj:
+        assert torch.equal(traj[key], torch.cat([t0[key], t1[key]], 1)), key
+
+
+def test_tournament_through_rollouts_matches_the_reference_goldens(golden):
+    """eval_minimax.py:16-50 with the whole loop on the device: per-episode scores and lengths identical to the reference's"""
+    from ewn_gym_amd.tournament import evaluate
+    for rec in golden("g10_eval_loop.json"):
+        opp = {"kind": rec["opp"]}
+        if rec["opp_depth"]:
+            opp["max_depth"] = rec["opp_depth"]
+        r = evaluate({"kind": "minimax", "max_depth": rec["agent_depth"]}, opp, num=len(rec["scores"]), rng="mt19937")
+        assert r["engine"] == "ewn_step_k"
+        assert r["scores"].cpu().tolist() == rec["scores"]
+        assert r["lengths"].cpu().tolist() == rec["lengths"]
+        slow = evaluate({"kind": "minimax", "max_depth": rec["agent_depth"]}, opp, num=len(rec["scores"]), rng="mt19937", use_rollout=False)
+        assert slow["engine"] == "ewn_step" and torch.equal(slow["scores"], r["scores"]) and torch.equal(slow["lengths"], r["lengths"])

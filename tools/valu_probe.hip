@@ -17,33 +17,58 @@
 typedef unsigned long long u64;
 typedef uint32_t u32;
 
+#define F_v_xor_b32(r) "v_xor_b32 " r ", " r ", %8\n"
+#define F_v_and_or_b32(r) "v_and_or_b32 " r ", " r ", %8, %8\n"
+#define F_v_lshlrev_b32(r) "v_lshlrev_b32 " r ", 1, " r "\n"
+#define F_v_add_u32(r) "v_add_u32 " r ", " r ", %8\n"
+#define F_v_lshl_or_b32(r) "v_lshl_or_b32 " r ", " r ", 1, %8\n"
+#define F_v_xad_u32(r) "v_xad_u32 " r ", " r ", %8, %8\n"
+#define F_v_min_u32(r) "v_min_u32 " r ", " r ", %8\n"
+#define F_v_perm_b32(r) "v_perm_b32 " r ", " r ", %8, %8\n"
+#define F_v_ffbh_u32(r) "v_ffbh_u32 " r ", " r "\n"
+#define F_v_bcnt_u32_b32(r) "v_bcnt_u32_b32 " r ", " r ", %8\n"
+#define F_v_mad_u32_u24(r) "v_mad_u32_u24 " r ", " r ", %8, %8\n"
+#define F_v_mul_lo_u32(r) "v_mul_lo_u32 " r ", " r ", %8\n"
+#define F_v_mul_hi_u32(r) "v_mul_hi_u32 " r ", " r ", %8\n"
+#define F_v_cndmask_b32(r) "v_cndmask_b32 " r ", " r ", %8, vcc\n"
+#define F_v_cmp_lt_u32(r) "v_cmp_lt_u32 vcc, " r ", %8\n"
+#define F_v_mov_b32(r) "v_mov_b32 " r ", %8\n"
+#define F_v_mov_b32_dpp(r) "v_mov_b32_dpp " r ", " r " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+#define F_v_lshlrev_b64(r) "v_lshlrev_b64 " r ", 1, " r "\n"
+#define F_v_lshrrev_b64(r) "v_lshrrev_b64 " r ", 1, " r "\n"
+#define F_v_add_f64(r) "v_add_f64 " r ", " r ", %8\n"
+#define F_v_mul_f64(r) "v_mul_f64 " r ", " r ", %8\n"
+#define F_v_max_f64(r) "v_max_f64 " r ", " r ", %8\n"
+#define F_v_cmp_le_f64(r) "v_cmp_le_f64 vcc, " r ", %8\n"
+#define F_mix_cmp_cndmask(r) "v_cmp_lt_u32 vcc, " r ", %8\n v_cndmask_b32 " r ", " r ", %8, vcc\n"
 #define CLASSES(X) \
-    X(v_xor_b32,      32, "v_xor_b32 %0, %0, %1") \
-    X(v_and_or_b32,   32, "v_and_or_b32 %0, %0, %1, %1") \
-    X(v_lshlrev_b32,  32, "v_lshlrev_b32 %0, 1, %0") \
-    X(v_add_u32,      32, "v_add_u32 %0, %0, %1") \
-    X(v_lshl_or_b32,  32, "v_lshl_or_b32 %0, %0, 1, %1") \
-    X(v_xad_u32,      32, "v_xad_u32 %0, %0, %1, %1") \
-    X(v_min_u32,      32, "v_min_u32 %0, %0, %1") \
-    X(v_perm_b32,     32, "v_perm_b32 %0, %0, %1, %1") \
-    X(v_ffbh_u32,     32, "v_ffbh_u32 %0, %0") \
-    X(v_bcnt_u32_b32, 32, "v_bcnt_u32_b32 %0, %0, %1") \
-    X(v_mad_u32_u24,  32, "v_mad_u32_u24 %0, %0, %1, %1") \
-    X(v_mul_lo_u32,   32, "v_mul_lo_u32 %0, %0, %1") \
-    X(v_mul_hi_u32,   32, "v_mul_hi_u32 %0, %0, %1") \
-    X(v_cndmask_b32,  32, "v_cndmask_b32 %0, %0, %1, vcc") \
-    X(v_cmp_lt_u32,   32, "v_cmp_lt_u32 vcc, %0, %1") \
-    X(v_mov_b32,      32, "v_mov_b32 %0, %1") \
-    X(v_mov_b32_dpp,  32, "v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") \
-    X(v_lshlrev_b64,  64, "v_lshlrev_b64 %0, 1, %0") \
-    X(v_lshrrev_b64,  64, "v_lshrrev_b64 %0, 1, %0") \
-    X(v_add_f64,      -64, "v_add_f64 %0, %0, %1") \
-    X(v_mul_f64,      -64, "v_mul_f64 %0, %0, %1") \
-    X(v_max_f64,      -64, "v_max_f64 %0, %0, %1") \
-    X(v_cmp_le_f64,   -64, "v_cmp_le_f64 vcc, %0, %1")
+    X(v_xor_b32, 32) \
+    X(v_and_or_b32, 32) \
+    X(v_lshlrev_b32, 32) \
+    X(v_add_u32, 32) \
+    X(v_lshl_or_b32, 32) \
+    X(v_xad_u32, 32) \
+    X(v_min_u32, 32) \
+    X(v_perm_b32, 32) \
+    X(v_ffbh_u32, 32) \
+    X(v_bcnt_u32_b32, 32) \
+    X(v_mad_u32_u24, 32) \
+    X(v_mul_lo_u32, 32) \
+    X(v_mul_hi_u32, 32) \
+    X(v_cndmask_b32, 32) \
+    X(v_cmp_lt_u32, 32) \
+    X(v_mov_b32, 32) \
+    X(v_mov_b32_dpp, 32) \
+    X(v_lshlrev_b64, 64) \
+    X(v_lshrrev_b64, 64) \
+    X(v_add_f64, -64) \
+    X(v_mul_f64, -64) \
+    X(v_max_f64, -64) \
+    X(v_cmp_le_f64, -64) \
+    X(mix_cmp_cndmask, 32)
 
 enum {
-#define X(name, w, ins) OP_##name,
+#define X(name, w) OP_##name,
     CLASSES(X)
 #undef X
     OP_N
@@ -51,13 +76,15 @@ enum {
 
 struct ClassInfo { const char *name; int width; };
 static const ClassInfo INFO[OP_N] = {
-#define X(name, w, ins) { #name, w },
+#define X(name, w) { #name, w },
     CLASSES(X)
 #undef X
 };
 
-#define ONE(ins, reg, kk) asm volatile(ins : "+v"(reg) : "v"(kk) : "vcc")
-#define ROW(ins, r0, r1, r2, r3, r4, r5, r6, r7, kk) ONE(ins, r0, kk); ONE(ins, r1, kk); ONE(ins, r2, kk); ONE(ins, r3, kk); ONE(ins, r4, kk); ONE(ins, r5, kk); ONE(ins, r6, kk); ONE(ins, r7, kk)
+// ONE asm statement per 32 instructions: the compiler puts an s_nop between separate asm statements (4 issue cycles each)
+#define B8(F) F("%0") F("%1") F("%2") F("%3") F("%4") F("%5") F("%6") F("%7")
+#define B32(F) B8(F) B8(F) B8(F) B8(F)
+#define RUN(F, r0, r1, r2, r3, r4, r5, r6, r7, kk) asm volatile(B32(F) : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(kk) : "vcc")
 
 template <int OP>
 __global__ __launch_bounds__(256) void k_probe(u64 *out, int reps, u32 seed)
@@ -70,13 +97,11 @@ __global__ __launch_bounds__(256) void k_probe(u64 *out, int reps, u32 seed)
     const u64 t0 = __builtin_amdgcn_s_memtime();
     #pragma unroll 1
     for (int r = 0; r < reps; r++) {
-#define X(name, w, ins) \
+#define X(name, w) \
         if constexpr (OP == OP_##name) { \
-            _Pragma("unroll") for (int q = 0; q < 4; q++) { \
-                if constexpr (w == 32) { ROW(ins, a0, a1, a2, a3, a4, a5, a6, a7, k); } \
-                else if constexpr (w == 64) { ROW(ins, b0, b1, b2, b3, b4, b5, b6, b7, k); } \
-                else { ROW(ins, d0, d1, d2, d3, d4, d5, d6, d7, dk); } \
-            } \
+            if constexpr (w == 32) { RUN(F_##name, a0, a1, a2, a3, a4, a5, a6, a7, k); } \
+            else if constexpr (w == 64) { RUN(F_##name, b0, b1, b2, b3, b4, b5, b6, b7, k); } \
+            else { RUN(F_##name, d0, d1, d2, d3, d4, d5, d6, d7, dk); } \
         }
         CLASSES(X)
 #undef X
@@ -89,7 +114,7 @@ __global__ __launch_bounds__(256) void k_probe(u64 *out, int reps, u32 seed)
 
 typedef void (*probe_fn)(u64 *, int, u32);
 static probe_fn FN[OP_N] = {
-#define X(name, w, ins) k_probe<OP_##name>,
+#define X(name, w) k_probe<OP_##name>,
     CLASSES(X)
 #undef X
 };
@@ -112,7 +137,7 @@ int main(int argc, char **argv)
         for (int W = 1; W <= 8; W *= 2) {
             // W blocks per CU: each asks for a 1/W share of the CU's LDS (minus slack for W = 1 is not needed: one block per
             // CU is forced by asking for more than half)
-            const size_t lds = W == 1 ? 96 * 1024 : lds_cu / W - 512;
+            const size_t lds = W == 1 ? 96 * 1024 : (W == 8 ? 16 * 1024 : lds_cu / W - 1024); // W = 8: the wave slots (32 per CU) limit, not LDS
             const int blocks = cus * W;
             hipFuncSetAttribute((const void *)FN[op], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipMemset(dev, 0, (size_t)(2 + max_waves) * sizeof(u64));
@@ -129,7 +154,7 @@ int main(int argc, char **argv)
             hipMemcpy(host.data(), dev, (size_t)(2 + blocks * 4) * sizeof(u64), hipMemcpyDeviceToHost);
             std::vector<u64> c(host.begin() + 2, host.begin() + 2 + blocks * 4);
             std::sort(c.begin(), c.end());
-            const double med = (double)c[c.size() / 2], insts = (double)reps * 32.0;
+            const double med = (double)c[c.size() / 2], insts = (double)reps * (op == OP_mix_cmp_cndmask ? 64.0 : 32.0);
             printf(", \"w%d\": {\"wave_cycles_per_inst\": %.3f, \"issue_cycles_per_inst\": %.3f, \"kernel_ms\": %.4f}", W, med / insts, med / insts / W, ms);
         }
         printf("}%s\n", op + 1 < OP_N ? "," : "");
