@@ -17,17 +17,24 @@ class ExpectiMinimaxAgent(PolicyBase):
         self.heuristic = heuristic
         if kwargs.get("reference_quirks", True):
             reference_ctor_side_effect(cube_layer)
-        if heuristic == "sim_winrate":
-            raise ewn_gym_amd.EwnError("heuristic 'sim_winrate' (envs/minimax_ewn.py:215-238) is not built")
+        # 'sim_winrate' (envs/minimax_ewn.py:215-238): every leaf is 100 random playouts; their randomness is a per-agent key
+        # and a per-call counter (the reference draws from the never-seeded Python `random`): statistical parity
+        self._key = int(np.random.SeedSequence(kwargs.get("seed")).generate_state(2, np.uint32).view(np.uint64)[0])
+        self._calls = 0
+
+    def _search(self, boards, dice):
+        self._calls += 1
+        return self._ea.predict_minimax(boards, dice, self.max_depth, self.heuristic, cube_layer=self.cube_layer,
+                                        key=(self._key + self._calls * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
 
     def predict_batch(self, boards, dice, return_values=False):
-        acts, vals = self._ea.predict_minimax(boards, dice, self.max_depth, self.heuristic, cube_layer=self.cube_layer)
+        acts, vals = self._search(boards, dice)
         return (acts, vals) if return_values else acts
 
     def expectiminimax_root(self, obs):
         """(root value, action) of the search, i.e. expectiminimax(max_depth, TOP_LEFT, None, -inf, inf) upstream"""
         b, d = obs_arrays(obs)
-        acts, vals = self._ea.predict_minimax(b, d, self.max_depth, self.heuristic, cube_layer=self.cube_layer)
+        acts, vals = self._search(b, d)
         a = acts[0].cpu().numpy()
         return float(vals[0].item()), ([int(a[0]), int(a[1])] if a[0] >= 0 else None)
 

@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("EWN_HIP_LIB", os.path.join(HERE, "lib", "libewn_hip.s
 
 OPP = {"random": 0, "minimax": 1, "mcts": 2}
 RNG = {"mt19937": 0, "philox": 1}
-HEUR = {"hybrid": 0, "min_dist": 1, "two_min_dist": 2, "attk": 3}
+HEUR = {"hybrid": 0, "min_dist": 1, "two_min_dist": 2, "attk": 3, "sim_winrate": 4}
 INFO_MESSAGES = {
     0: None,
     1: "Invalid move for player! End the game.",      # envs/ewn.py:448
@@ -23,7 +23,7 @@ INFO_MESSAGES = {
 EXPORTS = ["ewn_abi_version", "ewn_strerror", "ewn_rng_words", "ewn_step_scratch_bytes", "ewn_tables_bytes",
            "ewn_build_tables", "ewn_init_aux", "ewn_reset",
            "ewn_step", "ewn_legal_actions", "ewn_apply_action", "ewn_playout_wins", "ewn_evaluate", "ewn_predict_minimax", "ewn_predict_random",
-           "ewn_predict_mcts", "ewn_step_k", "ewn_step_k_supported"]
+           "ewn_predict_mcts", "ewn_step_k", "ewn_step_k_supported", "ewn_predict_minimax_sim"]
 AGENT = {"random": 0, "minimax": 1}
 
 
@@ -100,6 +100,7 @@ def load():
         "ewn_predict_minimax": (i32, [i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp]),
         "ewn_predict_random": (i32, [i32, i32, i32, vp, vp, u64, u32, vp, i32, vp, vp]),
         "ewn_predict_mcts": (i32, [i32, i32, i32, vp, vp, i32, i32, u64, vp, vp, vp, vp]),
+        "ewn_predict_minimax_sim": (i32, [i32, i32, i32, vp, vp, i32, u64, vp, vp, vp, vp]),
         "ewn_step_k": (i32, [cfgp, stp, i32, i32, i32, C.POINTER(EwnRolloutOut), vp]),
         "ewn_step_k_supported": (i32, [cfgp, i32, i32]),
     }

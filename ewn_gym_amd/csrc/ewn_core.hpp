@@ -248,17 +248,25 @@ EWN_DEV double evaluate(const Geom &g, const GState<NW> &s, int heur)
 // 3 = CHANCE below MIN.  Alpha/beta are passed by value THROUGH chance nodes exactly
 // as the reference does (unsound but behaviour-defining); depth also
 // decrements at chance nodes; the dice loop is the hard-coded 1..6 (App. D5).
-template <int NW, int DEPTH, int KIND, bool ROOT>
-__device__ double search(const Geom &g, const GState<NW> &s, int dice, double alpha, double beta, int heur, int &bflag, int &bdir)
+// The value of a leaf is `leaf(g, s)`: EvalLeaf = MinimaxEnv.evaluate(heuristic) for the four board heuristics; the
+// 'sim_winrate' heuristic (random playouts, envs/minimax_ewn.py:215-238) brings its own functor (ewn_kernels.hip: SimLeaf).
+template <int NW>
+struct EvalLeaf {
+    int heur;
+    EWN_DEV double operator()(const Geom &g, const GState<NW> &s) { return evaluate<NW>(g, s, heur); }
+};
+
+template <int NW, int DEPTH, int KIND, bool ROOT, class Leaf>
+__device__ double search(const Geom &g, const GState<NW> &s, int dice, double alpha, double beta, Leaf &leaf, int &bflag, int &bdir)
 {
     if constexpr (DEPTH == 0) {
-        return evaluate<NW>(g, s, heur);
+        return leaf(g, s);
     } else {
-        if (is_win<NW>(g, s)) return evaluate<NW>(g, s, heur);
+        if (is_win<NW>(g, s)) return leaf(g, s);
         if constexpr (KIND >= 2) {
             double expected = 0.0;
             for (int d = 1; d <= 6; d++) {
-                const double v = search<NW, DEPTH - 1, (KIND == 2 ? 1 : 0), false>(g, s, d, alpha, beta, heur, bflag, bdir);
+                const double v = search<NW, DEPTH - 1, (KIND == 2 ? 1 : 0), false>(g, s, d, alpha, beta, leaf, bflag, bdir);
                 expected = expected + v / 6.0;
             }
             return expected;
@@ -268,7 +276,7 @@ __device__ double search(const Geom &g, const GState<NW> &s, int dice, double al
             for_each_legal<SIDE, NW>(g, s, dice, [&](int flag, int k, int dir) -> bool {
                 GState<NW> c = s;
                 apply_move<SIDE, NW>(g, c, k, dir);
-                const double v = search<NW, DEPTH - 1, (SIDE == 0 ? 2 : 3), false>(g, c, dice, alpha, beta, heur, bflag, bdir);
+                const double v = search<NW, DEPTH - 1, (SIDE == 0 ? 2 : 3), false>(g, c, dice, alpha, beta, leaf, bflag, bdir);
                 if constexpr (SIDE == 0) {
                     if (v > best) { best = v; if constexpr (ROOT) { bflag = flag; bdir = dir; } }
                     if (best > alpha) alpha = best;

@@ -58,7 +58,16 @@ struct FastTab {
     // ring index -> ring index of the same square seen from the other side (board rotated by 180 degrees, envs/ewn.py:289-296);
     // an involution.  The rollout kernel uses it to hand the AGENT's position to the same search (ewn_rollout.hpp).
     uint8_t rot[64];
+    // ring index -> max(row, col) of the canonical square = the REAL square's distance to the real bottom-right corner, which is
+    // what the shaped training env's evaluate() measures for both sides (envs/training_ewn.py:94-96, envs/minimax_ewn.py:67-76)
+    uint8_t dtl[64];
 };
+
+// table images per board size: [heuristic image][variant]; heuristic images: 'hybrid', 'min_dist', 'attk' (functions of each side's
+// (level, count); 'two_min_dist' needs the second-nearest cube as well and stays on the generic kernels)
+#define FAST_HEUR_IMAGES 3
+EWN_DEV int fast_heur_image_dev(int heur) { return heur == 0 ? 0 : (heur == 1 ? 1 : 2); }
+static inline int fast_heur_image(int heur) { return heur == 0 ? 0 : (heur == 1 ? 1 : (heur == 3 ? 2 : -1)); }
 
 // LDS / device image size: the struct padded to 4 KiB so the LDS-DMA copy needs no tail handling
 #define FAST_TAB_BYTES(S) ((int)((sizeof(FastTab<S>) + 4095) / 4096 * 4096))
@@ -92,8 +101,9 @@ EWN_DEV int popc_m(u64 m) { return __popcll(m); }
 // variant 0: max_depth 3 (a leaf is evaluate()).  variant 1: max_depth 4, where the search goes one chance node and one
 // depth-0 max node further before evaluating (classical_policies/minimax.py:19-73): a non-terminal leaf is then
 // sum over six dice of evaluate()/6, added in order -- the same tables with that value in place of evaluate().
+// heur: EWN_H_HYBRID (0), EWN_H_MIN_DIST (1) or EWN_H_ATTK (3): the leaf value as envs/minimax_ewn.py:29-213 computes it
 template <int S>
-static int build_fast_tables(FastTab<S> *T, int variant = 0)
+static int build_fast_tables(FastTab<S> *T, int variant = 0, int heur = 0)
 {
     constexpr int IXN = FastTab<S>::IXN;
     memset(T, 0, sizeof(*T));
@@ -142,6 +152,7 @@ static int build_fast_tables(FastTab<S> *T, int variant = 0)
     }
     for (int q = 0; q < 64; q++) T->real_of_ring[q] = q < S * S ? (uint8_t)(S * S - 1 - rm_of_ring[q]) : 0;
     for (int q = 0; q < 64; q++) T->rot[q] = q < S * S ? (uint8_t)ring_of_rm[S * S - 1 - rm_of_ring[q]] : 0;
+    for (int q = 0; q < 64; q++) { const int c = q < S * S ? rm_of_ring[q] : 0; T->dtl[q] = (uint8_t)((c / S > c % S) ? c / S : c % S); }
     T->init_posP = T->init_posN = 0x4040ull << 48; // bytes 6 and 7: no such cube
     {
         int cnt = 1;
@@ -172,6 +183,10 @@ static int build_fast_tables(FastTab<S> *T, int variant = 0)
             volatile double s0 = 0.0 + x;
             volatile double s1 = s0 - y;
             double ev = s1;
+            // the integer heuristics return Python ints; every later use (val / 6, comparisons, the returned root value) sees the
+            // same number as a double.  min_dist: (L - mdP) - (L - mdN) with L - md = t + 1 (:126-127); attk: -(nP + nN) (:212)
+            if (heur == 1) ev = (double)((tp + 1) - (tn + 1));
+            if (heur == 3) ev = (double)(-(np_ + nn));
             if (variant == 1) { volatile double sixth = ev / 6.0, acc = 0.0; for (int d = 0; d < 6; d++) acc = acc + sixth; ev = acc; }
             e[(size_t)(tp * 8 + np_) * IXN + (tn * 8 + nn)] = ev;
             all.push_back(ev);

@@ -73,7 +73,8 @@ static inline int check_cfg(const ewn_config *cfg, Geom &g, KCfg &k)
     if (cfg->rng_kind != EWN_RNG_MT19937 && cfg->rng_kind != EWN_RNG_PHILOX) return EWN_EINVAL;
     if (cfg->opponent_kind == EWN_OPP_MINIMAX) {
         if (cfg->max_depth < 1 || cfg->max_depth > EWN_MAX_DEPTH) return EWN_EUNSUPPORTED;
-        if (cfg->heuristic < 0 || cfg->heuristic > EWN_H_ATTK) return EWN_EUNSUPPORTED;
+        if (cfg->heuristic < 0 || cfg->heuristic > EWN_H_SIM_WINRATE) return EWN_EUNSUPPORTED;
+        if (cfg->heuristic == EWN_H_SIM_WINRATE && cfg->max_depth > EWN_SIM_WINRATE_MAX_DEPTH) return EWN_EUNSUPPORTED;
     }
     // the searches and rollouts roll dice 1..6 (minimax.py:68, mcts.py:29): cube_num < 6 raises IndexError upstream
     if (cfg->opponent_kind != EWN_OPP_RANDOM && g.CN < 6) return EWN_EUNSUPPORTED;

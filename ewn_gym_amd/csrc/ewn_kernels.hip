@@ -122,7 +122,8 @@ __device__ void policy_minimax(const Geom &g, const GState<NW> &s, int dice, int
 {
     const GState<NW> cst = canonicalize<NW>(g, s); // the policy always plays TOP_LEFT (envs/ewn.py:291-295)
     oflag = 0; odir = 0;
-    const double v = search<NW, DEPTH, 0, true>(g, cst, dice, -__builtin_inf(), __builtin_inf(), heur, oflag, odir);
+    EvalLeaf<NW> leaf = { heur };
+    const double v = search<NW, DEPTH, 0, true>(g, cst, dice, -__builtin_inf(), __builtin_inf(), leaf, oflag, odir);
     if (value) *value = v;
 }
 
@@ -416,8 +417,10 @@ __global__ __launch_bounds__(BS) void k_predict_minimax(Geom g, int M, const int
     int f = -1, d = -1;
     double v = 0.0;
     const int dc = dice[m];
-    if (s.aliveP != 0 && dc >= 1 && dc <= g.CN)
-        v = search<NW, DEPTH, 0, true>(g, s, dc, -__builtin_inf(), __builtin_inf(), heur, f, d);
+    if (s.aliveP != 0 && dc >= 1 && dc <= g.CN) {
+        EvalLeaf<NW> leaf = { heur };
+        v = search<NW, DEPTH, 0, true>(g, s, dc, -__builtin_inf(), __builtin_inf(), leaf, f, d);
+    }
     actions[2 * m] = (int8_t)f; actions[2 * m + 1] = (int8_t)d;
     if (values) values[m] = v;
 }
@@ -514,6 +517,57 @@ EWN_DEV void rollout_ply(const Geom &g, GState<NW> &s, PlayoutRng &ps)
     for (int i = 0; i < pick; i++) m &= m - 1;
     const int slot = __ffs((int)m) - 1;
     if (n > 0) apply_move<SIDE, NW>(g, s, slot < 3 ? k0 : k1, slot < 3 ? slot : slot - 3);
+}
+
+// The 'sim_winrate' heuristic as a search leaf: MinimaxEnv.simulate (envs/minimax_ewn.py:215-238) -- num_simulations = 100
+// uniformly random playouts from the leaf position, value = playouts TOP_LEFT won / 100.  As upstream, no terminal +-10 here
+// (evaluate() returns simulate() before that test, :37-38: a finished position scores 1.0 or 0.0), and the side to move in a
+// playout is `current_player` of the policy's private env, which simulate() flips before EVERY move and never restores: the
+// first mover of a playout is whoever did not make the last move of the previous one, across leaves too.  The search never sets
+// current_player, so that chain is all there is; it starts at TOP_LEFT (the env right after construction).  One generator per
+// search, drawn from in the order of the depth-first search.  Statistical parity with the reference (unseeded Python
+// `random`); bit-exact with oracle/ewn_oracle.c, which mirrors it.
+template <int NW>
+struct SimLeaf {
+    PlayoutRng ps;
+    int cur;      // 0 TOP_LEFT, 1 BOTTOM_RIGHT: MinimaxEnv.current_player
+    int nsims;
+    EWN_DEV double operator()(const Geom &g, const GState<NW> &s0)
+    {
+        int wins = 0;
+        for (int sim = 0; sim < nsims; sim++) {
+            GState<NW> s = s0;
+            for (int ply = 0; ply < 4096 && !is_win<NW>(g, s); ply++) {
+                cur ^= 1;                                               // self.switch_player()
+                if (cur == 0) rollout_ply<0, NW>(g, s, ps); else rollout_ply<1, NW>(g, s, ps);
+            }
+            wins += ((s.occP & g.corner_br) || s.occN == 0) ? 1 : 0;    // :233-235
+        }
+        return (double)wins / (double)nsims;
+    }
+};
+
+// ExpectiMinimaxAgent(heuristic='sim_winrate').predict: one thread per observation (a leaf costs 100 playouts; nobody runs this
+// at scale, the reference included).  active (may be NULL): lanes of a split-phase step that need no reply are skipped.
+template <int NW, int DEPTH>
+__global__ __launch_bounds__(64) void k_predict_minimax_sim(Geom g, int M, const int8_t *boards, const int8_t *dice, const uint8_t *active,
+                                                            const u32 *obs_id, u64 key, int nsims, int8_t *actions, double *values)
+{
+    const int m = blockIdx.x * 64 + threadIdx.x;
+    if (m >= M || (active && !active[m])) return;
+    GState<NW> s;
+    decode_board<NW>(g, boards + (size_t)m * g.cells, s);
+    int f = -1, d = -1;
+    double v = 0.0;
+    const int dc = dice[m];
+    if (s.aliveP != 0 && dc >= 1 && dc <= g.CN) {
+        SimLeaf<NW> leaf;
+        leaf.ps.seed(PlayoutRng::obs_word(obs_id ? obs_id[m] : (u32)m, 0x53494D57u, key), 0u);
+        leaf.cur = 0; leaf.nsims = nsims;
+        v = search<NW, DEPTH, 0, true>(g, s, dc, -__builtin_inf(), __builtin_inf(), leaf, f, d);
+    }
+    actions[2 * m] = (int8_t)f; actions[2 * m + 1] = (int8_t)d;
+    if (values) values[m] = v;
 }
 
 // classical_policies/mcts.py:21-45, any cube_layer: thread (observation m, root move i, playout r)
@@ -625,6 +679,21 @@ static void launch_minimax(const Geom &g, int M, const int8_t *boards, const int
     }
 }
 
+template <int NW>
+static int launch_minimax_sim(const Geom &g, int M, const int8_t *boards, const int8_t *dice, const uint8_t *active, const u32 *obs_id,
+                              u64 key, int depth, int8_t *actions, double *values, hipStream_t s)
+{
+    const dim3 grid((unsigned)((M + 63) / 64));
+    switch (depth) {
+    case 1: k_predict_minimax_sim<NW, 1><<<grid, 64, 0, s>>>(g, M, boards, dice, active, obs_id, key, EWN_SIM_WINRATE_PLAYOUTS, actions, values); break;
+    case 2: k_predict_minimax_sim<NW, 2><<<grid, 64, 0, s>>>(g, M, boards, dice, active, obs_id, key, EWN_SIM_WINRATE_PLAYOUTS, actions, values); break;
+    case 3: k_predict_minimax_sim<NW, 3><<<grid, 64, 0, s>>>(g, M, boards, dice, active, obs_id, key, EWN_SIM_WINRATE_PLAYOUTS, actions, values); break;
+    case 4: k_predict_minimax_sim<NW, 4><<<grid, 64, 0, s>>>(g, M, boards, dice, active, obs_id, key, EWN_SIM_WINRATE_PLAYOUTS, actions, values); break;
+    default: return EWN_EUNSUPPORTED;
+    }
+    return launch_status();
+}
+
 extern "C" {
 
 int ewn_abi_version(void) { return EWN_ABI_VERSION; }
@@ -645,20 +714,27 @@ int64_t ewn_tables_bytes(int board_size, int cube_layer)
 {
     Geom g;
     if (!make_geom(board_size, cube_layer, g)) return 0;
-    return 2 * fast_tables_bytes(board_size, cube_layer); // two images: max_depth <= 3, then max_depth 4 (ewn_fast.hpp)
+    // per heuristic image ('hybrid', 'min_dist', 'attk') two variants: max_depth 1-3 and 5, then max_depth 4 and 6 (ewn_fast.hpp)
+    return 2 * FAST_HEUR_IMAGES * fast_tables_bytes(board_size, cube_layer);
 }
 
 int ewn_build_tables(int board_size, int cube_layer, void *host_out)
 {
     if (!host_out) return EWN_ENULL;
     if (ewn_tables_bytes(board_size, cube_layer) <= 0) return EWN_EUNSUPPORTED;
-    int rc = -1;
-    switch (board_size) {
-    case 5: rc = build_fast_tables<5>((FastTab<5> *)host_out, 0) | build_fast_tables<5>((FastTab<5> *)((int8_t *)host_out + FAST_TAB_BYTES(5)), 1); break;
-    case 6: rc = build_fast_tables<6>((FastTab<6> *)host_out, 0) | build_fast_tables<6>((FastTab<6> *)((int8_t *)host_out + FAST_TAB_BYTES(6)), 1); break;
-    case 7: rc = build_fast_tables<7>((FastTab<7> *)host_out, 0) | build_fast_tables<7>((FastTab<7> *)((int8_t *)host_out + FAST_TAB_BYTES(7)), 1); break;
-    case 8: rc = build_fast_tables<8>((FastTab<8> *)host_out, 0) | build_fast_tables<8>((FastTab<8> *)((int8_t *)host_out + FAST_TAB_BYTES(8)), 1); break;
-    }
+    int rc = 0;
+    static const int heur_of_image[FAST_HEUR_IMAGES] = { EWN_H_HYBRID, EWN_H_MIN_DIST, EWN_H_ATTK };
+    for (int hi = 0; hi < FAST_HEUR_IMAGES; hi++)
+        for (int variant = 0; variant < 2; variant++) {
+            void *dst = (int8_t *)host_out + (size_t)(hi * 2 + variant) * fast_tables_bytes(board_size, cube_layer);
+            switch (board_size) {
+            case 5: rc |= build_fast_tables<5>((FastTab<5> *)dst, variant, heur_of_image[hi]); break;
+            case 6: rc |= build_fast_tables<6>((FastTab<6> *)dst, variant, heur_of_image[hi]); break;
+            case 7: rc |= build_fast_tables<7>((FastTab<7> *)dst, variant, heur_of_image[hi]); break;
+            case 8: rc |= build_fast_tables<8>((FastTab<8> *)dst, variant, heur_of_image[hi]); break;
+            default: rc = -1;
+            }
+        }
     return rc == 0 ? EWN_OK : EWN_EUNSUPPORTED;
 }
 
@@ -675,7 +751,8 @@ int64_t ewn_step_scratch_bytes(const ewn_config *cfg)
     const int rc = check_cfg(cfg, g, k);
     if (rc) return rc;
     const int64_t N = k.N;
-    if (cfg->opponent_kind != EWN_OPP_MCTS)   // MT kind with auto-reset: the refill queue of the lean step kernel (ewn_step_d3.hpp)
+    const bool split = cfg->opponent_kind == EWN_OPP_MCTS || (cfg->opponent_kind == EWN_OPP_MINIMAX && cfg->heuristic == EWN_H_SIM_WINRATE);
+    if (!split)   // MT kind with auto-reset: the refill queue of the lean step kernel (ewn_step_d3.hpp)
         return (cfg->rng_kind == EWN_RNG_MT19937 && cfg->autoreset) ? mtq_bytes(k.N) : 0;
     // phase u8 | cdice i8 | act i8x2 | (pad to 8) | obs_id u32 | wins i32x6 | cboard i8[cells]
     return ((N * 4 + 7) / 8) * 8 + N * 4 + N * 24 + N * g.cells;
@@ -746,6 +823,8 @@ static int mcts_launch(const Geom &g, int M, const int8_t *boards, const int8_t 
     return launch_status();
 }
 
+static const void *fast_image(const void *tables, int S, int L, int max_depth, int heur);
+
 int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, const ewn_step_out *out, void *scratch, void *stream)
 {
     Geom g; KCfg k;
@@ -761,17 +840,19 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
     KScratch sc = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     // MT kind with auto-reset: the step kernel flags the lanes whose spare window it consumed; k_mt_refill rebuilds them right after
     const bool refill = cfg->rng_kind == EWN_RNG_MT19937 && cfg->autoreset;
-    if (cfg->opponent_kind == EWN_OPP_MCTS) {
+    const bool sim_opp = cfg->opponent_kind == EWN_OPP_MINIMAX && cfg->heuristic == EWN_H_SIM_WINRATE;
+    const bool split = cfg->opponent_kind == EWN_OPP_MCTS || sim_opp; // the opponent's policy runs as kernels of its own between two half steps
+    if (split) {
         if (!scratch) return EWN_ENULL;
         carve_scratch(g, k, scratch, sc);
     }
     const size_t lds = (size_t)2 * BS * g.cells;
-    if (cfg->opponent_kind != EWN_OPP_MCTS) {
+    if (!split) {
         const bool fast = st->tables && fast_tables_bytes(g.S, g.L) > 0 && cfg->opponent_kind == EWN_OPP_MINIMAX &&
-                          cfg->max_depth <= 6 && cfg->heuristic == EWN_H_HYBRID;
+                          cfg->max_depth <= 6 && fast_heur_image(cfg->heuristic) >= 0;
         const bool lean_random = st->tables && fast_tables_bytes(g.S, g.L) > 0 && cfg->opponent_kind == EWN_OPP_RANDOM;
-        if (fast && (cfg->max_depth == 4 || cfg->max_depth == 6)) ks.tables = (const int8_t *)st->tables + fast_tables_bytes(g.S, g.L); // the max_depth-4 image
-        if ((fast || lean_random) && !cfg->shaped && d3_threads_per_game(k.N) > 0) {
+        if (fast) ks.tables = fast_image(st->tables, g.S, g.L, cfg->max_depth, cfg->heuristic); // the image of this heuristic and depth class
+        if ((fast || lean_random) && d3_threads_per_game(k.N) > 0) {
             // the lean fused kernel: canonical ring space end to end, T lanes per game (ewn_step_d3.hpp / ewn_step_d3.hip).
             // MT kind with auto-reset: window refills are extra blocks of the same launch (needs the caller's scratch).
             const bool fused_refill = refill && scratch != nullptr;
@@ -794,7 +875,10 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
               (k_step<2, 1, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)));
         rc = launch_status();
         if (rc) return rc;
-        rc = mcts_launch(g, k.N, sc.cboard, sc.cdice, sc.phase, k.nsim_total, k.key, sc.obs_id, sc.act, sc.wins, s);
+        if (sim_opp) {
+            BY_NW(g, rc = launch_minimax_sim<1>(g, k.N, sc.cboard, sc.cdice, sc.phase, sc.obs_id, k.key, k.depth, sc.act, nullptr, s),
+                  rc = launch_minimax_sim<2>(g, k.N, sc.cboard, sc.cdice, sc.phase, sc.obs_id, k.key, k.depth, sc.act, nullptr, s));
+        } else rc = mcts_launch(g, k.N, sc.cboard, sc.cdice, sc.phase, k.nsim_total, k.key, sc.obs_id, sc.act, sc.wins, s);
         if (rc) return rc;
         BY_NW(g, (k_step<1, 2, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)),
               (k_step<2, 2, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)));
@@ -808,10 +892,13 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
     return rc;
 }
 
-// table image of a 'hybrid' search of the given max_depth: max_depth 4 and 6 read the second image (leaves averaged over six dice)
-static const void *fast_image(const void *tables, int S, int L, int max_depth)
+// table image of a search with the given heuristic and max_depth: max_depth 4 and 6 read the image's second variant (leaves
+// averaged over six dice); NULL for a heuristic without images
+static const void *fast_image(const void *tables, int S, int L, int max_depth, int heur = EWN_H_HYBRID)
 {
-    return (max_depth == 4 || max_depth == 6) ? (const void *)((const int8_t *)tables + fast_tables_bytes(S, L)) : tables;
+    const int hi = fast_heur_image(heur);
+    if (!tables || hi < 0) return nullptr;
+    return (const int8_t *)tables + (size_t)(hi * 2 + ((max_depth == 4 || max_depth == 6) ? 1 : 0)) * fast_tables_bytes(S, L);
 }
 
 // which k_rollout_d3 instantiation serves (cfg, agent): EWN_OK and the template selectors, or why not
@@ -819,7 +906,7 @@ static int rollout_plan(const ewn_config *cfg, const Geom &g, const KCfg &k, int
 {
     if (fast_tables_bytes(g.S, g.L) <= 0 || cfg->shaped) return EWN_EUNSUPPORTED;
     if (cfg->opponent_kind == EWN_OPP_RANDOM) opp = 1;
-    else if (cfg->opponent_kind == EWN_OPP_MINIMAX && cfg->heuristic == EWN_H_HYBRID) opp = cfg->max_depth > 4 ? 2 : 0;
+    else if (cfg->opponent_kind == EWN_OPP_MINIMAX && fast_heur_image(cfg->heuristic) >= 0) opp = cfg->max_depth > 4 ? 2 : 0;
     else return EWN_EUNSUPPORTED;
     if (agent_kind == EWN_AGENT_RANDOM) agent = 0;
     else if (agent_kind == EWN_AGENT_MINIMAX) {
@@ -863,8 +950,8 @@ int ewn_step_k(const ewn_config *cfg, const ewn_state *st, int K, int agent_kind
     RollBuf rb;
     memset(&rb, 0, sizeof(rb));
     rb.board = st->board; rb.dice = st->dice; rb.done = st->done; rb.rng = st->rng;
-    rb.tables = opp == 1 ? st->tables : fast_image(st->tables, g.S, g.L, cfg->max_depth);
-    rb.agent_tables = agent == 0 ? rb.tables : fast_image(st->tables, g.S, g.L, agent_max_depth);
+    rb.tables = opp == 1 ? st->tables : fast_image(st->tables, g.S, g.L, cfg->max_depth, cfg->heuristic);
+    rb.agent_tables = agent == 0 ? rb.tables : fast_image(st->tables, g.S, g.L, agent_max_depth, EWN_H_HYBRID);
     if (out) {
         rb.t_board = out->board; rb.t_dice = out->dice; rb.t_action = out->action; rb.t_reward = out->reward;
         rb.t_term = out->terminated; rb.t_trunc = out->truncated; rb.t_info = out->info;
@@ -964,12 +1051,20 @@ int ewn_predict_minimax(int board_size, int cube_layer, int M, const int8_t *boa
     int rc = query_geom(board_size, cube_layer, M, boards, g);
     if (rc) return rc;
     if (max_depth < 1) return EWN_EINVAL;
-    if (max_depth > EWN_MAX_DEPTH || heuristic < 0 || heuristic > EWN_H_ATTK || g.CN < 6) return EWN_EUNSUPPORTED;
+    if (max_depth > EWN_MAX_DEPTH || heuristic < 0 || heuristic > EWN_H_SIM_WINRATE || g.CN < 6) return EWN_EUNSUPPORTED;
+    if (heuristic == EWN_H_SIM_WINRATE && max_depth > EWN_SIM_WINRATE_MAX_DEPTH) return EWN_EUNSUPPORTED;
     if (M == 0) return EWN_OK;
     if (!dice || !actions) return EWN_ENULL;
     hipStream_t s = (hipStream_t)stream;
-    if (tables && fast_tables_bytes(g.S, g.L) > 0 && max_depth <= 6 && heuristic == EWN_H_HYBRID) {
-        if (max_depth == 4 || max_depth == 6) tables = (const int8_t *)tables + fast_tables_bytes(g.S, g.L); // the max_depth-4 image
+    if (heuristic == EWN_H_SIM_WINRATE) {
+        // the playout randomness: one generator per observation from (index, sim_key); ewn_predict_minimax has no key argument,
+        // ewn_predict_minimax_sim (below) takes one
+        BY_NW(g, rc = launch_minimax_sim<1>(g, M, boards, dice, nullptr, nullptr, 0, max_depth, actions, values, s),
+              rc = launch_minimax_sim<2>(g, M, boards, dice, nullptr, nullptr, 0, max_depth, actions, values, s));
+        return rc;
+    }
+    if (tables && fast_tables_bytes(g.S, g.L) > 0 && max_depth <= 6 && fast_heur_image(heuristic) >= 0) {
+        tables = fast_image(tables, g.S, g.L, max_depth, heuristic);
         switch (g.S) {
         case 5: k_predict_minimax_fast<5><<<GRID(M), BS, FAST_TAB_BYTES(5), s>>>(g, M, boards, dice, max_depth, actions, values, tables); break;
         case 6: k_predict_minimax_fast<6><<<GRID(M), BS, FAST_TAB_BYTES(6), s>>>(g, M, boards, dice, max_depth, actions, values, tables); break;
@@ -981,6 +1076,22 @@ int ewn_predict_minimax(int board_size, int cube_layer, int M, const int8_t *boa
     BY_NW(g, launch_minimax<1>(g, M, boards, dice, max_depth, heuristic, actions, values, s),
           launch_minimax<2>(g, M, boards, dice, max_depth, heuristic, actions, values, s));
     return launch_status();
+}
+
+int ewn_predict_minimax_sim(int board_size, int cube_layer, int M, const int8_t *boards, const int8_t *dice, int max_depth, uint64_t key,
+                            const uint32_t *obs_id, int8_t *actions, double *values, void *stream)
+{
+    Geom g;
+    int rc = query_geom(board_size, cube_layer, M, boards, g);
+    if (rc) return rc;
+    if (max_depth < 1) return EWN_EINVAL;
+    if (max_depth > EWN_SIM_WINRATE_MAX_DEPTH || g.CN < 6) return EWN_EUNSUPPORTED;
+    if (M == 0) return EWN_OK;
+    if (!dice || !actions) return EWN_ENULL;
+    hipStream_t s = (hipStream_t)stream;
+    BY_NW(g, rc = launch_minimax_sim<1>(g, M, boards, dice, nullptr, obs_id, key, max_depth, actions, values, s),
+          rc = launch_minimax_sim<2>(g, M, boards, dice, nullptr, obs_id, key, max_depth, actions, values, s));
+    return rc;
 }
 
 int ewn_predict_random(int board_size, int cube_layer, int M, const int8_t *boards, const int8_t *dice, uint64_t key,

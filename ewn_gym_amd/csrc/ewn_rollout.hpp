@@ -184,10 +184,26 @@ __global__ __launch_bounds__(D3_BS) void k_rollout_d3(RollCfg c, RollBuf B)
             if (B.t_info) B.t_info[o] = (uint8_t)info;
         }
         if (want_board) {
+            // A wave's games are one contiguous, 16-byte aligned span of LDS (64 / T games x S*S bytes): the wave copies its own
+            // span out and no block-wide barrier is needed, so the waves of a block drift apart freely (LDS operations of one
+            // wave execute in program order).  The last, partial block of the grid and an unaligned row take the block copy.
             if (live) d3_encode<S, T>(Tb, s, sub, mine);
-            __syncthreads();
-            block_copy_out(B.t_board + ((size_t)kstep * c.N + g0) * CELLS, lds, ng * CELLS);
-            __syncthreads();
+            int8_t *row = B.t_board + ((size_t)kstep * c.N + g0) * CELLS;
+            constexpr int WB = (64 / T) * CELLS;       // bytes per wave
+            static_assert(WB % 16 == 0, "a wave's span of boards is a whole number of 16-byte pieces");
+            if (ng == GPB && (((uintptr_t)row) & 15) == 0) {
+                __builtin_amdgcn_wave_barrier();
+                const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+                const uint4 *src = (const uint4 *)(lds + wv * WB);
+                uint4 *dst = (uint4 *)(row + wv * WB);
+                #pragma unroll
+                for (int i = 0; i < (WB / 16 + 63) / 64; i++) { const int j = i * 64 + ln; if (j < WB / 16) dst[j] = src[j]; }
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                __syncthreads();
+                block_copy_out(row, lds, ng * CELLS);
+                __syncthreads();
+            }
         }
     }
     // ---- the state goes back to HBM once

@@ -15,10 +15,11 @@ int ewn_launch_step_d3(const ewn_config *cfg, const Geom &g, const KCfg &k, cons
     // step role's ~45 k.  Measured at 65 536 lanes: 256 refill blocks (two regions each, two chains back to back) 38.4 us
     // per launch, 512 blocks 26.5 us.
     const int refill_blocks = fused_refill ? step_blocks : 0;
-    D3Cfg dc = { k.N, k.rng_kind, k.autoreset, k.lane_offset, k.depth, refill_blocks, k.seed_stride, k.W, k.reward, k.key };
+    D3Cfg dc = { k.N, k.rng_kind, k.autoreset, k.lane_offset, k.depth, refill_blocks, k.seed_stride, k.W, k.reward, k.key,
+                 cfg->shaped ? 1 : 0, k.refresh, k.illegal_reward };
     D3Buf db = { st->board, st->dice, st->done, st->rng, tables, actions, out->reward, out->terminated,
                  out->truncated, out->info, out->terminal_board, out->terminal_dice, out->random_action,
-                 fused_refill ? scratch : nullptr };
+                 fused_refill ? scratch : nullptr, cfg->shaped ? st->prev_score : nullptr, cfg->shaped ? st->tolerance : nullptr };
     const dim3 grid((unsigned)(step_blocks + refill_blocks));
     // LDS: boards + terminal boards | tables | decode scatter area | (MT) this block's parked refill requests; a refill block needs (W+1) x 65 words
     size_t l3 = (((size_t)2 * gpb * g.cells + 15) & ~(size_t)15) + (size_t)gpb * 16; // + d3_decode's 16 bytes per game

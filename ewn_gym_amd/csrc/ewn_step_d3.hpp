@@ -429,13 +429,39 @@ struct D3Cfg {
     u32 seed_stride, W;
     double reward;
     u64 key;
+    int shaped, refresh;     // MiniMaxHeuristicEnv.step (envs/training_ewn.py:43-99); refresh: prev_score re-evaluated on auto-reset
+    double illegal_reward;
 };
 
 struct D3Buf {
     int8_t *board; int8_t *dice; uint8_t *done; u32 *rng; const void *tables; const int8_t *actions;
     double *reward; uint8_t *terminated; uint8_t *truncated; uint8_t *info; int8_t *tboard; int8_t *tdice; int8_t *ract;
     void *mtq; // MT kind with auto-reset: the refill hand-off area (scratch), else NULL
+    double *prev_score; int32_t *tolerance; // shaped env only
 };
+
+// MinimaxEnv.evaluate('hybrid') of the REAL position as the shaped training env calls it (agent_player = TOP_LEFT,
+// envs/training_ewn.py:94-96, envs/minimax_ewn.py:56-86), for a position that is not won or lost: both sides' distance to the real
+// bottom-right corner = max(row, col) of the canonical square (table dtl), fp64 in the reference's order of operations.
+// The agent is the canonical BOTTOM_RIGHT side (posN), the opponent the canonical TOP_LEFT side (posP).
+template <int S>
+EWN_DEV double d3_shaped_score(const FastTab<S> *Tb, const RState<S> &s)
+{
+    u32 da[6], dq[6];
+    #pragma unroll
+    for (int k = 0; k < 6; k++) { da[k] = Tb->dtl[pk_get(s.posN, k) & 63]; dq[k] = Tb->dtl[pk_get(s.posP, k) & 63]; }
+    u32 mda = 255u, mdo = 255u;
+    int na = 0, no = 0;
+    #pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const bool aa = !(pk_get(s.posN, k) & PK_OFF), ao = !(pk_get(s.posP, k) & PK_OFF);
+        mda = aa ? min(mda, da[k]) : mda; na += aa ? 1 : 0;
+        mdo = ao ? min(mdo, dq[k]) : mdo; no += ao ? 1 : 0;
+    }
+    const double a = (double)(S - (int)mda) * (1.0 / (double)na);   // score += (L - md+) * (1 / n+)
+    const double b = (double)(S - (int)mdo) * (1.0 / (double)no);   // score -= (L - md-) * (1 / n-)
+    return (0.0 + a) - b;
+}
 
 #ifndef D3_BS
 #define D3_BS 256
@@ -578,7 +604,8 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
     const bool live = game < c.N, writer = sub == 0;
 
     uint4 hdr = make_uint4(0u, 0u, 0u, 0u);
-    int dice = 1, aflag = 0, adir = 0;
+    int dice = 1, aflag = 0, adir = 0, tol = 0;
+    double prev = 0.0;
     bool frozen = false;
     if (live) {
         hdr = *rng_hdr_ptr(B.rng, game);
@@ -586,6 +613,7 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
         frozen = B.done[game] != 0;
         const uint16_t a2 = ((const uint16_t *)B.actions)[game];
         aflag = (int8_t)(a2 & 0xff); adir = (int8_t)(a2 >> 8);
+        if (c.shaped) { tol = B.tolerance[game]; prev = B.prev_score[game]; }
     }
     // boards: request them now, put them into LDS after the RNG work below, whose ~200 issue slots (one Philox block) then
     // run while the data is on its way instead of in the agent half
@@ -623,7 +651,14 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
         // agent half, envs/ewn.py:438-458 (the agent is the canonical BOTTOM_RIGHT side)
         const int k = pk_cube(pk_sel<S>(Tb, s.posN, dice), aflag == 1);
         const int q = (adir >= 0 && adir <= 2) ? Tb->nbn[adir][pk_get(s.posN, k)] : 255; // no cube at all: byte 6 -> 255
-        if (q == 255) { reward = -c.reward; term = 1; trunc = 1; info = EWN_INFO_INVALID_PLAYER; }
+        if (q == 255) {
+            if (c.shaped) { // envs/training_ewn.py:48-56: an illegal move costs tolerance; the game goes on until it is used up
+                const int t = tol - 1;
+                if (writer) B.tolerance[game] = t;
+                if (t <= 0) { reward = -c.reward; term = 1; trunc = 1; info = EWN_INFO_INVALID_PLAYER; }
+                else { reward = c.illegal_reward; info = EWN_INFO_TOLERANCE; }
+            } else { reward = -c.reward; term = 1; trunc = 1; info = EWN_INFO_INVALID_PLAYER; }
+        }
         else {
             rs_move<S, false>(s, k, q);
             if (q == Tb->ri_origin || s.P == 0) { reward = c.reward; term = 1; info = EWN_INFO_WON; }
@@ -651,7 +686,14 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
         const int q = Tb->nbp[odir][pk_get(s.posP, k)];
         rs_move<S, true>(s, k, q);
         if (q == CELLS - 1 || s.N == 0) { reward = -c.reward; term = 1; info = EWN_INFO_LOST; }
-        else dice = r.randint(1, 7);
+        else {
+            dice = r.randint(1, 7);
+            if (c.shaped) { // envs/training_ewn.py:94-96: reward = evaluate() - prev_score
+                const double cur = d3_shaped_score<S>(Tb, s);
+                reward = cur - prev;
+                if (writer) B.prev_score[game] = cur;
+            }
+        }
     }
     if (live && B.tboard) { if (active) d3_encode<S, T>(Tb, s, sub, mine_t); else if (writer) for (int i = 0; i < CELLS; i++) mine_t[i] = mine[i]; }
     if (live && writer && B.tdice) B.tdice[game] = (int8_t)dice;
@@ -668,6 +710,7 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
                 }
                 d3_init_state<S>(Tb, s);
                 dice = r.first_dice(6);
+                if (c.shaped && c.refresh && writer) B.prev_score[game] = d3_shaped_score<S>(Tb, s);
             }
             else if (writer) B.done[game] = 1;
         }

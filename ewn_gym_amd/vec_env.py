@@ -59,7 +59,7 @@ class VecEWN:
         if opp not in OPP:
             raise _lib.EwnError("opponent policy %r is not supported by the HIP engine (random, minimax, mcts)" % opp)
         if heuristic not in HEUR:
-            raise _lib.EwnError("heuristic %r is not supported (hybrid, min_dist, two_min_dist, attk)" % heuristic)
+            raise _lib.EwnError("heuristic %r is not supported (hybrid, min_dist, two_min_dist, attk, sim_winrate)" % heuristic)
         self.N, self.S, self.L = int(n_lanes), int(board_size), int(cube_layer)
         self.cube_num = self.L * (self.L + 1) // 2
         self.cfg = EwnConfig(self.S, self.L, self.N, OPP[opp], int(max_depth), HEUR[heuristic], int(num_simulations),
@@ -259,13 +259,22 @@ def evaluate(boards, heuristic="hybrid", cube_layer=3):
     return out
 
 
-def predict_minimax(boards, dice, max_depth, heuristic="hybrid", cube_layer=3, use_tables=True):
+def predict_minimax(boards, dice, max_depth, heuristic="hybrid", cube_layer=3, use_tables=True, key=0, obs_id=None):
+    """ExpectiMinimaxAgent.predict on M observations -> (actions int8 [M,2], root values f64 [M]).  key / obs_id select the
+    playouts' randomness of the 'sim_winrate' heuristic (ignored otherwise)."""
     lib = _lib.load()
     if heuristic not in HEUR:
         raise _lib.EwnError("heuristic %r is not supported" % heuristic)
     b, d, M, S, dev = _prep(boards, dice)
     acts = torch.zeros((M, 2), dtype=torch.int8, device=dev)
     vals = torch.zeros(M, dtype=torch.float64, device=dev)
+    if heuristic == "sim_winrate":
+        ids = None
+        if obs_id is not None:
+            ids = torch.from_numpy(np.asarray(obs_id, dtype=np.uint32).reshape(-1).view(np.int32).copy()).to(dev)
+        check(lib.ewn_predict_minimax_sim(S, cube_layer, M, _ptr(b), _ptr(d), int(max_depth), C.c_uint64(key), _ptr(ids), _ptr(acts),
+                                          _ptr(vals), _stream()), "ewn_predict_minimax_sim")
+        return acts, vals
     tables = search_tables(S, cube_layer, dev) if use_tables else None
     check(lib.ewn_predict_minimax(S, cube_layer, M, _ptr(b), _ptr(d), int(max_depth), HEUR[heuristic], _ptr(acts),
                                   _ptr(vals), _ptr(tables), _stream()), "ewn_predict_minimax")

@@ -41,7 +41,7 @@ extern "C" {
 #define EWN_EINVAL (-1)      /* bad argument / unsupported configuration (the reference asserts, envs/ewn.py:47) */
 #define EWN_ENULL (-2)       /* required pointer is NULL */
 #define EWN_ELAUNCH (-3)     /* kernel launch failed (hipGetLastError != hipSuccess) */
-#define EWN_EUNSUPPORTED (-4)/* valid in the reference, not built here (e.g. board_size > 8, 'sim_winrate') */
+#define EWN_EUNSUPPORTED (-4)/* valid in the reference, not built here (e.g. board_size > 8, 'sim_winrate' deeper than 4) */
 
 /* opponent_kind: constants/policy.py:4-10 (uct / alpha_zero are out of scope) */
 #define EWN_OPP_RANDOM 0
@@ -57,6 +57,10 @@ extern "C" {
 #define EWN_H_MIN_DIST 1
 #define EWN_H_TWO_MIN_DIST 2
 #define EWN_H_ATTK 3
+#define EWN_H_SIM_WINRATE 4 /* MinimaxEnv.simulate as the search leaf (envs/minimax_ewn.py:36-37, 215-238): 100 random playouts per
+                               leaf; searches only (ewn_evaluate answers it through ewn_playout_wins); max_depth <= 4 */
+#define EWN_SIM_WINRATE_PLAYOUTS 100 /* MinimaxEnv.num_simulations, envs/minimax_ewn.py:20 */
+#define EWN_SIM_WINRATE_MAX_DEPTH 4
 
 /* info codes of ewn_step: the messages of envs/ewn.py:448,454,473,478 and envs/training_ewn.py:56 */
 #define EWN_INFO_NONE 0
@@ -226,6 +230,13 @@ int ewn_evaluate(int board_size, int cube_layer, int M, const int8_t *boards, in
  * A position that is already won/lost returns action {-1,-1} and value = evaluate(). */
 int ewn_predict_minimax(int board_size, int cube_layer, int M, const int8_t *boards, const int8_t *dice, int max_depth,
                         int heuristic, int8_t *actions, double *values, const void *tables, void *stream);
+
+/* The same with heuristic = 'sim_winrate' and an explicit key / per-observation stream id for the playouts' randomness (one
+ * Philox block {0, obs_id (NULL = index), 0, 'SIMW'} per observation seeds one generator, drawn from in the order of the
+ * depth-first search).  values [M] = root value (may be NULL).  Statistical parity with the reference (unseeded Python
+ * `random`, envs/minimax_ewn.py:222-225); bit-exact with oracle/ewn_oracle.c, which mirrors it. */
+int ewn_predict_minimax_sim(int board_size, int cube_layer, int M, const int8_t *boards, const int8_t *dice, int max_depth, uint64_t key,
+                            const uint32_t *obs_id, int8_t *actions, double *values, void *stream);
 
 /* RandomAgent.predict (classical_policies/random_policy.py:11-15) as a stateless policy:
  * uniform legal action from Philox ctr={step + (step_dev ? *step_dev : 0), lane_offset+i, 'AGNT', 0}, key.

@@ -14,7 +14,7 @@ _LIB = None
 
 OPP = {"random": 0, "minimax": 1, "mcts": 2}
 RNG = {"mt19937": 0, "philox": 1}
-HEUR = {"hybrid": 0, "min_dist": 1, "two_min_dist": 2, "attk": 3}
+HEUR = {"hybrid": 0, "min_dist": 1, "two_min_dist": 2, "attk": 3, "sim_winrate": 4}
 INFO_MESSAGES = {
     0: None,
     1: "Invalid move for player! End the game.",
@@ -75,6 +75,20 @@ def predict_minimax(boards, dice, max_depth, heuristic="hybrid", cube_layer=3):
                                           C.c_int(HEUR[heuristic]), _p(acts), _p(vals), _p(leaves))
     assert rc == 0
     return acts, vals, leaves
+
+
+def predict_minimax_sim(boards, dice, max_depth, key=0, obs_id=None, nsims=100, cube_layer=3):
+    """ExpectiMinimaxAgent(heuristic='sim_winrate').predict with the HIP engine's playout generator"""
+    boards = _i8(boards)
+    M, S = boards.shape[0], boards.shape[1]
+    dice = _i8(dice)
+    acts = np.zeros((M, 2), np.int8)
+    vals = np.zeros(M, np.float64)
+    ids = None if obs_id is None else np.ascontiguousarray(obs_id, dtype=np.uint32)
+    rc = lib().ewn_oracle_predict_minimax_sim(C.c_int(S), C.c_int(cube_layer), C.c_int(M), _p(boards), _p(dice), C.c_int(max_depth),
+                                              C.c_uint64(key), _p(ids), C.c_int(nsims), _p(acts), _p(vals))
+    assert rc == 0
+    return acts, vals
 
 
 def evaluate(boards, heuristic="hybrid", cube_layer=3):

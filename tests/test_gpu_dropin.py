@@ -269,3 +269,27 @@ def test_mt_stream_exhaustion_is_reported():
     ok.reset(seeds=np.arange(64))
     ok.step(ok.sample_legal_actions(0))
     ok.check_rng()
+
+
+def test_sim_winrate_agent_through_the_drop_in_classes():
+    """ExpectiMinimaxAgent(heuristic='sim_winrate') and MinimaxEnv.evaluate('sim_winrate') exist and behave: a depth-1 agent
+    (max over root moves of 100-playout win rates) beats RandomAgent clearly more often than it loses."""
+    import envs
+    from classical_policies import ExpectiMinimaxAgent
+    from constants import ClassicalPolicy
+    agent = ExpectiMinimaxAgent(max_depth=1, cube_layer=3, board_size=5, heuristic="sim_winrate", seed=3)
+    env = envs.EinsteinWuerfeltNichtEnv(opponent_policy=ClassicalPolicy.random)
+    wins = 0
+    for ep in range(24):
+        obs, _ = env.reset(seed=ep)
+        for _ in range(60):
+            action, _ = agent.predict(obs)
+            assert action in env.get_legal_actions(env.current_player)
+            obs, reward, terminated, truncated, info = env.step(action)
+            if terminated:
+                wins += reward > 0
+                break
+    assert wins >= 16, wins
+    m = envs.MinimaxEnv()
+    v = m.evaluate("sim_winrate")
+    assert 0.0 <= v <= 1.0

@@ -675,3 +675,57 @@ def test_no_kernel_writes_outside_its_buffers(ea, monkeypatch):
         guarded.clear()
     vec_env._TABLES.clear()
     vec_env._TABLES.update(saved_tables)
+
+
+@pytest.mark.parametrize("heur", ["min_dist", "attk"])
+@pytest.mark.parametrize("S,depth,n", [(5, 1, 1500), (5, 2, 1500), (5, 3, 6000), (5, 4, 400), (5, 5, 60), (7, 3, 1500), (8, 4, 200), (6, 6, 6)])
+def test_integer_heuristics_on_the_table_driven_kernel(ea, heur, S, depth, n):
+    """'min_dist' and 'attk' (envs/minimax_ewn.py:88-131, 180-213) are functions of each side's (level, count) like 'hybrid':
+    the table-driven search runs them from their own table images; against the template recursion and the oracle."""
+    b, d = _random_positions(S, 3, n, 4000 + depth + S, max_steps=14 if S == 5 else 24)
+    fa, fv = ea.predict_minimax(b, d, depth, heur, use_tables=True)
+    oa, ov, _ = po.predict_minimax(b, d, depth, heur)
+    assert np.array_equal(cpu(fa), oa) and np.array_equal(bits(cpu(fv)), bits(ov))
+    if depth <= 4:
+        ga, gv = ea.predict_minimax(b, d, depth, heur, use_tables=False)
+        assert np.array_equal(cpu(ga), oa) and np.array_equal(bits(cpu(gv)), bits(ov))
+
+
+def test_generic_kernels_stay_covered(ea):
+    """use_tables=False keeps the template-recursive / bitboard kernels under test for the configurations the table-driven
+    kernel has taken over (shaped env, integer heuristics), and the lean kernel is run with them at its other lanes-per-game
+    choices (40 000 lanes: two per game)."""
+    _lockstep(ea, 800, 30, shaped=True, illegal_move_tolerance=3, reward=10.0, illegal_move_reward=-0.25, rng="mt19937", use_tables=False)
+    _lockstep(ea, 600, 25, shaped=True, shaped_refresh_on_reset=True, opponent_policy="minimax", max_depth=3, rng="philox", use_tables=False)
+    _lockstep(ea, 500, 20, opponent_policy="minimax", max_depth=3, heuristic="min_dist", rng="philox", use_tables=False)
+    _lockstep(ea, 500, 20, opponent_policy="minimax", max_depth=4, heuristic="attk", rng="mt19937")
+    _lockstep(ea, 300, 20, board_size=7, opponent_policy="minimax", max_depth=3, heuristic="min_dist", rng="philox", philox_key=8)
+    _lockstep(ea, 128, 10, opponent_policy="minimax", max_depth=5, heuristic="attk", rng="philox", philox_key=9)
+    _lockstep(ea, 40000, 8, shaped=True, illegal_move_tolerance=2, reward=10.0, opponent_policy="minimax", max_depth=3, rng="philox",
+              philox_key=10, check_terminal=False)
+
+
+@pytest.mark.parametrize("S,L,depth,n", [(5, 3, 1, 64), (5, 3, 2, 48), (5, 3, 3, 24), (7, 4, 2, 16), (6, 3, 4, 3)])
+def test_sim_winrate_as_a_search_leaf(ea, S, L, depth, n):
+    """ExpectiMinimaxAgent(heuristic='sim_winrate') (classical_policies/minimax.py:22-23 -> envs/minimax_ewn.py:36-37, 215-238):
+    every leaf is 100 random playouts whose first mover follows the reference's current_player chain.  Bit-exact against the
+    oracle's literal restatement (same generator); parity with the reference itself is statistical (unseeded Python random)."""
+    b, d = _random_positions(S, L, n, 600 + depth, max_steps=20)
+    d = np.minimum(d, 6).astype(np.int8)
+    ids = np.arange(n, dtype=np.uint32) * 31 + 5
+    acts, vals = ea.predict_minimax(b, d, depth, "sim_winrate", cube_layer=L, key=0xABCDEF12345, obs_id=ids)
+    oa, ov = po.predict_minimax_sim(b, d, depth, key=0xABCDEF12345, obs_id=ids, cube_layer=L)
+    assert np.array_equal(cpu(acts), oa)
+    assert np.array_equal(bits(cpu(vals)), bits(ov))
+    v = cpu(vals)
+    assert ((v >= 0.0) & (v <= 1.0)).all()          # a win rate, never the +-10 of the board heuristics
+    if depth == 1:                                  # value = max over root moves of a playout win rate: multiples of 1/100
+        assert np.allclose(v * 100, np.round(v * 100))
+    with pytest.raises(ea.EwnError):
+        ea.predict_minimax(b, d, 5, "sim_winrate", cube_layer=L)
+
+
+def test_step_with_sim_winrate_opponent(ea):
+    """the env's minimax opponent with heuristic='sim_winrate': split-phase step (agent half, search kernel, opponent half)"""
+    _lockstep(ea, 96, 8, opponent_policy="minimax", max_depth=2, heuristic="sim_winrate", rng="philox", philox_key=21)
+    _lockstep(ea, 40, 6, opponent_policy="minimax", max_depth=1, heuristic="sim_winrate", rng="mt19937", philox_key=22)

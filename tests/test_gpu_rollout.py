@@ -87,6 +87,11 @@ def test_rollout_other_table_depths(ea, depth):
     _rollout_vs_oracle(ea, 700, 100, 500, 6, 2, opponent_policy="minimax", max_depth=depth, rng="philox", philox_key=depth)
 
 
+@pytest.mark.parametrize("heur,depth", [("min_dist", 3), ("attk", 2), ("attk", 4)])
+def test_rollout_integer_heuristic_opponents(ea, heur, depth):
+    _rollout_vs_oracle(ea, 700, 100, 500, 6, 2, opponent_policy="minimax", max_depth=depth, heuristic=heur, rng="philox", philox_key=depth)
+
+
 def test_rollout_depth5_opponent(ea):
     _rollout_vs_oracle(ea, 200, 0, 96, 5, 2, opponent_policy="minimax", max_depth=5, rng="philox", philox_key=55)
 

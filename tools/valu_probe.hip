@@ -108,7 +108,12 @@ __global__ __launch_bounds__(256) void k_probe(u64 *out, int reps, u32 seed)
     }
     const u64 t1 = __builtin_amdgcn_s_memtime();
     const u32 sink = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ (u32)(b0 ^ b1 ^ b2 ^ b3 ^ b4 ^ b5 ^ b6 ^ b7) ^ (u32)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);
-    if ((threadIdx.x & 63) == 0) out[2 + blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+    if ((threadIdx.x & 63) == 0) {
+        // HW_ID (register 4): wave_id[3:0] simd_id[5:4] pipe[7:6] cu_id[11:8] sh_id[12] se_id[15:13] ...; XCC_ID (register 20)
+        const u32 hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+        u64 *o = out + 2 + (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 3;
+        o[0] = t0; o[1] = t1; o[2] = ((u64)xcc << 32) | hw;
+    }
     if (sink == 0x12345678u) out[1] = sink; // keeps the chains alive
 }
 
@@ -128,19 +133,18 @@ int main(int argc, char **argv)
     const size_t lds_cu = 160 * 1024;
     u64 *dev = nullptr;
     const int max_waves = cus * 8 * 4;
-    if (hipMalloc(&dev, (size_t)(2 + max_waves) * sizeof(u64)) != hipSuccess) return 1;
-    std::vector<u64> host(2 + max_waves);
+    if (hipMalloc(&dev, (size_t)(2 + 3 * max_waves) * sizeof(u64)) != hipSuccess) return 1;
+    std::vector<u64> host(2 + 3 * max_waves);
     printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz\": %d, \"reps\": %d, \"insts_per_wave\": %d, \"classes\": {\n", prop.gcnArchName, cus,
            prop.clockRate / 1000, reps, reps * 32);
     for (int op = 0; op < OP_N; op++) {
         printf("  \"%s\": {\"width\": %d", INFO[op].name, INFO[op].width < 0 ? 64 : INFO[op].width);
         for (int W = 1; W <= 8; W *= 2) {
-            // W blocks per CU: each asks for a 1/W share of the CU's LDS (minus slack for W = 1 is not needed: one block per
-            // CU is forced by asking for more than half)
-            const size_t lds = W == 1 ? 96 * 1024 : (W == 8 ? 16 * 1024 : lds_cu / W - 1024); // W = 8: the wave slots (32 per CU) limit, not LDS
+            // W blocks per CU on average: the grid size alone sets the occupancy (every block fits at once: tiny LDS, few
+            // registers); the hardware ids each wave records tell how evenly the dispatcher spread them over the SIMDs
+            const size_t lds = 1024;
             const int blocks = cus * W;
-            hipFuncSetAttribute((const void *)FN[op], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipMemset(dev, 0, (size_t)(2 + max_waves) * sizeof(u64));
+            hipMemset(dev, 0, (size_t)(2 + 3 * max_waves) * sizeof(u64));
             hipLaunchKernelGGL(FN[op], dim3(blocks), dim3(256), lds, 0, dev, 64, 1u); // warm-up (code cache)
             hipDeviceSynchronize();
             hipEvent_t e0, e1;
@@ -151,11 +155,27 @@ int main(int argc, char **argv)
             if (hipDeviceSynchronize() != hipSuccess) { fprintf(stderr, "launch failed\n"); return 1; }
             float ms = 0;
             hipEventElapsedTime(&ms, e0, e1);
-            hipMemcpy(host.data(), dev, (size_t)(2 + blocks * 4) * sizeof(u64), hipMemcpyDeviceToHost);
-            std::vector<u64> c(host.begin() + 2, host.begin() + 2 + blocks * 4);
+            const int nw = blocks * 4;
+            hipMemcpy(host.data(), dev, (size_t)(2 + 3 * nw) * sizeof(u64), hipMemcpyDeviceToHost);
+            std::vector<u64> c(nw);
+            u64 tmin = ~0ull, tmax = 0;
+            std::vector<int> per_simd(8 * 8 * 2 * 16 * 4 * 2, 0); // xcc, se, sh, cu, simd (generous)
+            for (int i = 0; i < nw; i++) {
+                const u64 t0 = host[2 + 3 * i], t1 = host[3 + 3 * i], id = host[4 + 3 * i];
+                c[i] = t1 - t0; tmin = std::min(tmin, t0); tmax = std::max(tmax, t1);
+                const u32 hw = (u32)id, xcc = (u32)(id >> 32) & 7u;
+                const u32 simd = (hw >> 4) & 3u, cu = (hw >> 8) & 15u, sh = (hw >> 12) & 1u, se = (hw >> 13) & 7u;
+                per_simd[(((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd]++;
+            }
             std::sort(c.begin(), c.end());
+            int used = 0, wmax = 0;
+            for (int v : per_simd) { if (v) used++; wmax = std::max(wmax, v); }
             const double med = (double)c[c.size() / 2], insts = (double)reps * (op == OP_mix_cmp_cndmask ? 64.0 : 32.0);
-            printf(", \"w%d\": {\"wave_cycles_per_inst\": %.3f, \"issue_cycles_per_inst\": %.3f, \"kernel_ms\": %.4f}", W, med / insts, med / insts / W, ms);
+            // chip-wide rate from the wall clock: the figure the roofline uses (no assumption about the s_memtime tick)
+            const double rate = (double)nw * insts / (ms * 1e-3);
+            printf(", \"w%d\": {\"wave_ticks_per_inst\": %.3f, \"kernel_ms\": %.4f, \"span_ticks\": %llu, \"simds_used\": %d, \"max_waves_on_a_simd\": %d, "
+                   "\"wave_insts_per_s\": %.4g, \"ns_per_inst_per_simd\": %.4f}", W, med / insts, ms, (unsigned long long)(tmax - tmin), used, wmax,
+                   rate, 1e9 * 1024.0 / rate);
         }
         printf("}%s\n", op + 1 < OP_N ? "," : "");
     }

@@ -29,5 +29,6 @@ if __name__ == "__main__":
         os.makedirs(d, exist_ok=True)
         json.dump(res, open(os.path.join(d, "valu_probe.json"), "w"), indent=1)
     for k, v in res["classes"].items():
-        print("%-18s w1 %.2f  w2 %.2f  w4 %.2f  w8 %.2f  issue cycles / wave-instruction / SIMD" % (
-            k, v["w1"]["issue_cycles_per_inst"], v["w2"]["issue_cycles_per_inst"], v["w4"]["issue_cycles_per_inst"], v["w8"]["issue_cycles_per_inst"]))
+        print("%-18s " % k + "  ".join("w%d %.3g/s (%.2f ns/inst/SIMD, %d SIMDs, <=%d waves each, wave %.2f ticks/inst)" % (
+            w, v["w%d" % w]["wave_insts_per_s"], v["w%d" % w]["ns_per_inst_per_simd"], v["w%d" % w]["simds_used"],
+            v["w%d" % w]["max_waves_on_a_simd"], v["w%d" % w]["wave_ticks_per_inst"]) for w in (1, 2, 4, 8)))
