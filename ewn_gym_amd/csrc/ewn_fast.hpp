@@ -202,11 +202,14 @@ static int build_fast_tables(FastTab<S> *T, int variant = 0, int heur = 0)
         volatile double q = v / 6.0;
         T->val[i] = v; T->val6[i] = q;
     }
+    // the rank of -10: 1 for 'hybrid' and 'min_dist' (nothing lies below it), not for 'attk' (-(6 + 6) = -12 does)
+    const uint16_t m10 = (uint16_t)(1 + (std::lower_bound(all.begin(), all.end(), -10.0) - all.begin()));
     for (int ix = 0; ix < IXN; ix++)
         for (int iy = 0; iy < IXN; iy++) {
             const bool used = (ix % 8) >= 1 && (ix % 8) <= 6 && (iy % 8) >= 1 && (iy % 8) <= 6;
-            T->rank[ix * IXN + iy] = used ? (uint16_t)(1 + (std::lower_bound(all.begin(), all.end(), e[(size_t)ix * IXN + iy]) - all.begin())) : 1;
+            // a slot no position maps to (count 0 = the side has lost its last cube, envs/minimax_ewn.py:45-47) answers -10
+            T->rank[ix * IXN + iy] = used ? (uint16_t)(1 + (std::lower_bound(all.begin(), all.end(), e[(size_t)ix * IXN + iy]) - all.begin())) : m10;
         }
-    T->rank[0] = 1023; T->rank[1] = 1; // unused (level 0, count 0) slots that d3_search's leaf index is steered to
+    T->rank[0] = 1023; T->rank[1] = m10; // unused (level 0, count 0) slots that d3_search's leaf index is steered to: "no such reply", -10
     return 0;
 }
