@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--mode", default="auto", choices=["auto", "rollout", "step"],
                     help="rollout: ewn_step_k, --steps-per-launch env steps per kernel launch; step: one ewn_step launch per env step; "
                          "auto: rollout where the engine has it for the configuration, else step")
-    ap.add_argument("--steps-per-launch", type=int, default=25, help="rollout mode: env steps per ewn_step_k launch")
+    ap.add_argument("--steps-per-launch", type=int, default=50, help="rollout mode: env steps per ewn_step_k launch")
     ap.add_argument("--no-trajectory", action="store_true",
                     help="rollout mode: do not write the per-step trajectory (only final state and per-lane counters)")
     ap.add_argument("--agent", default="legal", choices=["legal", "uniform6"],

@@ -19,7 +19,11 @@ from .vec_env import VecEWN
 
 
 def main():
-    ap = argparse.ArgumentParser()
+    ap = argparse.ArgumentParser(description="Trainer for EWN on VecEWN lanes (counterpart of the reference's train.py)")
+    # train.py:174-184 selects the algorithm with a sub-command; A2C is the one built here
+    ap.add_argument("algorithm", nargs="?", default="A2C", choices=["A2C", "PPO"], help="A2C (PPO is refused: not built)")
+    ap.add_argument("--checkpoint", default=None, help="path of a checkpoint written by this trainer to resume from (train.py:137-139, 248-251)")
+    ap.add_argument("--model_seed", type=int, default=None, help="seed of the policy initialisation and sampling (default: --env_seed)")
     ap.add_argument("--num_envs", "-ne", type=int, default=4096, help="lanes per GPU")
     ap.add_argument("--n_steps", "-n", type=int, default=5)
     ap.add_argument("--learning_rate", "-lr", type=float, default=3e-4)
@@ -36,9 +40,13 @@ def main():
     ap.add_argument("--illegal_move_tolerance", type=int, default=10)
     ap.add_argument("--reference_quirks", action="store_true",
                     help="reproduce MinimaxEnv's ctor-argument dropping: RandomAgent opponent, reward 1.0 (SURVEY App. D1)")
-    ap.add_argument("--seed", type=int, default=9487)
+    ap.add_argument("--seed", "--env_seed", dest="seed", type=int, default=9487)
     ap.add_argument("--save_dir", default="models")
     a = ap.parse_args()
+    if a.algorithm == "PPO":
+        # train.py:178-183, 50-62: SB3's PPO (clipped surrogate, minibatch epochs, GAE 0.95).  Only the A2C update is built on
+        # the device-resident rollout; refusing is better than silently training something else under that name.
+        ap.error("PPO is not built in this trainer (only the A2C sub-command of train.py:174-184 is); use A2C")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -53,7 +61,11 @@ def main():
                  illegal_move_tolerance=a.illegal_move_tolerance, autoreset=True, lane_offset=lo,
                  seed_stride=a.num_envs * world, philox_key=a.seed, shaped_refresh_on_reset=not a.reference_quirks)
     env.reset(seeds=lane_seeds(lo, hi, a.seed).cuda())
-    trainer = A2CTrainer(env, n_steps=a.n_steps, learning_rate=a.learning_rate, seed=a.seed)
+    trainer = A2CTrainer(env, n_steps=a.n_steps, learning_rate=a.learning_rate, seed=a.seed if a.model_seed is None else a.model_seed)
+    if a.checkpoint is not None:      # train.py:137-139: resume the model (and here the optimiser and the step counter too)
+        trainer.load(a.checkpoint)
+        if rank == 0:
+            print(json.dumps({"resumed_from": a.checkpoint, "timesteps": trainer.num_timesteps * world}), flush=True)
     best = -1.0
     for epoch in range(a.epoch_num):
         stats = trainer.learn(a.timesteps_per_epoch // world)   # dict of the last update's statistics

@@ -138,6 +138,14 @@ def playout_wins(boards, first_player, n_sims=100, key=0, cube_layer=3):
     return wins
 
 
+def prng_draws(c1, x, count, tag=0x4D435453, key=0):
+    """(dice - 1, 24-bit fraction) of `count` plies of one playout stream"""
+    d = np.zeros(count, np.uint8)
+    f = np.zeros(count, np.uint32)
+    lib().ewn_oracle_prng_draws(C.c_uint32(c1), C.c_uint32(x), C.c_uint32(tag), C.c_uint64(key), C.c_int(count), _p(d), _p(f))
+    return d, f
+
+
 def philox(ctr, key):
     c = np.asarray(ctr, np.uint32)
     k = np.asarray(key, np.uint32)

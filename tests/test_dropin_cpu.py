@@ -1,7 +1,10 @@
 """Host-side API surface of the drop-in packages (no GPU): names, signatures, enums."""
 import inspect
+import os
 
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_constants():
@@ -62,3 +65,15 @@ def test_spaces_compat():
         assert md.contains(md.sample())
     d = sp.Discrete(7, start=1)
     assert d.contains(1) and d.contains(7) and not d.contains(0) and not d.contains(8)
+
+
+def test_trainer_cli_refuses_ppo_and_accepts_the_reference_flag_names():
+    """train.py:174-184: the algorithm is a sub-command; only A2C is built, PPO must be refused, not silently replaced"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "ewn_gym_amd.train_a2c", "PPO"], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 2 and "PPO is not built" in r.stderr
+    h = subprocess.run([sys.executable, "-m", "ewn_gym_amd.train_a2c", "--help"], cwd=ROOT, capture_output=True, text=True).stdout
+    for flag in ("--checkpoint", "--env_seed", "--model_seed", "--num_envs", "--n_steps", "--timesteps_per_epoch", "--illegal_move_tolerance",
+                 "--opponent_policy", "--max_depth", "--epoch_num", "--learning_rate"):
+        assert flag in h, flag

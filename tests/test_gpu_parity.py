@@ -729,3 +729,19 @@ def test_step_with_sim_winrate_opponent(ea):
     """the env's minimax opponent with heuristic='sim_winrate': split-phase step (agent half, search kernel, opponent half)"""
     _lockstep(ea, 96, 8, opponent_policy="minimax", max_depth=2, heuristic="sim_winrate", rng="philox", philox_key=21)
     _lockstep(ea, 40, 6, opponent_policy="minimax", max_depth=1, heuristic="sim_winrate", rng="mt19937", philox_key=22)
+
+
+def test_g9b_mcts_playout_policy_chi_square_vs_reference(ea, golden):
+    """The HIP playouts against the reference's (oracle/gen_golden_mcts.py: 72 positions, 5000 / 1500 reference playouts per root
+    move), 20 000 HIP playouts per root move: aggregate chi-square over all cells at p > 1e-3 and no systematic bias."""
+    from scipy.stats import chi2
+    from test_oracle_golden import _mcts_chi2
+    g = golden("g9b_mcts_large.json")
+    for (S, L) in sorted({(r["S"], r["L"]) for r in g}):
+        recs = [r for r in g if (r["S"], r["L"]) == (S, L)]
+        nsim = 20000
+        _, wins = ea.predict_mcts(boards_of(recs, S), [r["dice"] for r in recs], num_simulations=nsim, num_env_copies=1, key=99, cube_layer=L)
+        wins = cpu(wins)
+        c2, cells, bias = _mcts_chi2(recs, lambda i, j: int(wins[i, j]), nsim)
+        assert chi2.sf(c2, cells) > 1e-3, (S, c2, cells)
+        assert abs(bias) < 3.5, (S, bias)

@@ -76,3 +76,29 @@ def test_a2c_learns_to_avoid_illegal_moves():
     assert any(not torch.equal(a, b) for a, b in zip(p0, tr.model.parameters()))
     assert tr.num_timesteps == 300 * 5 * N
     assert after < 0.6 * before, (before, after)
+
+
+def test_checkpoint_resume(tmp_path):
+    """train.py:137-139 / --checkpoint: a saved trainer resumes with the same parameters, optimiser state and step count"""
+    import ewn_gym_amd as ea
+    from ewn_gym_amd.a2c import A2CTrainer
+    N = 1024
+
+    def make():
+        env = ea.VecEWN(N, opponent_policy="minimax", max_depth=2, rng="philox", shaped=True, reward=10.0, autoreset=True, philox_key=5,
+                        shaped_refresh_on_reset=True)
+        env.reset(seeds=torch.arange(N, dtype=torch.int32))
+        return A2CTrainer(env, n_steps=4, learning_rate=1e-3, seed=3)
+
+    a = make()
+    for _ in range(5):
+        a.collect_and_update()
+    path = str(tmp_path / "ckpt.pt")
+    a.save(path)
+    b = make()
+    b.load(path)
+    assert b.num_timesteps == a.num_timesteps == 5 * 4 * N
+    for p, q in zip(a.model.parameters(), b.model.parameters()):
+        assert torch.equal(p, q)
+    sa, sb = a.opt.state_dict()["state"], b.opt.state_dict()["state"]
+    assert sa.keys() == sb.keys() and all(torch.equal(sa[k]["square_avg"], sb[k]["square_avg"]) for k in sa)

@@ -202,3 +202,67 @@ def test_g13_cube_layers_4_and_5(golden):
         for rec in grp["traj"]:
             _check_traj(rec, "minimax", max_depth=rec["depth"], heuristic=rec["heuristic"])
     assert n >= 300
+
+
+def _mcts_chi2(recs, wins_of, nsim):
+    """Aggregate test of homogeneity over all (position, root move) cells: z = (p_ref - p_ours) / sigma_pooled per cell,
+    chi2 = sum z^2 with one degree of freedom per cell; also the mean z (a systematic bias of the playout policy moves every
+    cell the same way).  Cells whose pooled rate is 0 or 1 carry no information and are left out."""
+    z = []
+    for i, r in enumerate(recs):
+        for j, w in enumerate(r["wins"]):
+            p = (w + wins_of(i, j)) / (r["n"] + nsim)
+            if p <= 0.0 or p >= 1.0:
+                assert w / r["n"] == wins_of(i, j) / nsim
+                continue
+            z.append((w / r["n"] - wins_of(i, j) / nsim) / (p * (1 - p) * (1 / r["n"] + 1 / nsim)) ** 0.5)
+    z = np.array(z)
+    return float((z ** 2).sum()), len(z), float(z.mean() * len(z) ** 0.5)
+
+
+def test_g9b_mcts_playout_policy_chi_square_vs_reference(golden):
+    """72 positions x ~3.3 root moves x 5000 (5x5) / 1500 (7x7) playouts of the reference's MctsAgent.simulate
+    (classical_policies/mcts.py:21-45, oracle/gen_golden_mcts.py) against the same number of playouts of the mirrored
+    generator: aggregate chi-square at p > 1e-3 and no systematic bias (|sum z / sqrt(cells)| < 3.5).  A playout policy that is
+    off by one percent in win probability fails this (z per cell ~ 1, chi2 ~ 2 x cells); the per-cell 5-sigma check of G9 did not."""
+    from scipy.stats import chi2
+    g = golden("g9b_mcts_large.json")
+    assert len(g) >= 60 and sum(len(r["wins"]) for r in g) >= 180
+    for (S, L) in sorted({(r["S"], r["L"]) for r in g}):
+        recs = [r for r in g if (r["S"], r["L"]) == (S, L)]
+        nsim = recs[0]["n"]
+        acts, wins = po.predict_mcts(boards_of(recs, S), [r["dice"] for r in recs], num_simulations=nsim, num_env_copies=1, key=4242, cube_layer=L)
+        for i, r in enumerate(recs):
+            assert (wins[i, :len(r["wins"])] >= 0).all() and (wins[i, len(r["wins"]):] == -1).all()
+        c2, cells, bias = _mcts_chi2(recs, lambda i, j: int(wins[i, j]), nsim)
+        assert chi2.sf(c2, cells) > 1e-3, (S, c2, cells)
+        assert abs(bias) < 3.5, (S, bias)
+
+
+def test_playout_generator_dice_and_move_index_are_jointly_uniform():
+    """One 32-bit draw per ply yields both the dice (top of a 24-bit product) and the move index (its low 24 bits times the number
+    of legal moves): they come from ONE word, so their JOINT distribution is what has to be uniform, for every list length
+    n = 1..6, within a stream and across the streams of consecutive playouts; plus no serial correlation of successive dice."""
+    from scipy.stats import chi2
+    ds, fs = [], []
+    for x in range(400):                      # 400 playout streams of one observation, as the kernels seed them
+        d, f = po.prng_draws(12345, x, 3000, key=0xC0FFEE)
+        ds.append(d)
+        fs.append(f)
+    d, f = np.concatenate(ds).astype(np.int64), np.concatenate(fs).astype(np.int64)
+    N = len(d)
+    assert d.min() == 0 and d.max() == 5 and f.max() < (1 << 24)
+    for n in range(1, 7):
+        pick = (f * n) >> 24
+        assert pick.min() == 0 and pick.max() == n - 1
+        counts = np.bincount(d * n + pick, minlength=6 * n).astype(float)
+        e = N / (6 * n)
+        assert chi2.sf(((counts - e) ** 2 / e).sum(), 6 * n - 1) > 1e-4, n
+    # successive plies of a stream: (dice_t, dice_t+1) uniform on 36 cells; first plies across streams uniform as well
+    for arr in ds[:50]:
+        a = arr.astype(np.int64)
+        c = np.bincount(a[:-1] * 6 + a[1:], minlength=36).astype(float)
+        assert chi2.sf(((c - (len(a) - 1) / 36) ** 2 / ((len(a) - 1) / 36)).sum(), 35) > 1e-5
+    first = np.array([po.prng_draws(777, x, 1, key=5)[0][0] for x in range(6000)], dtype=np.int64)
+    c = np.bincount(first, minlength=6).astype(float)
+    assert chi2.sf(((c - 1000) ** 2 / 1000).sum(), 5) > 1e-4

@@ -134,18 +134,26 @@ def mix(body):
     return dict(total), dict(hot), len(insts), region
 
 
-def weighted_issue_cycles(counts, probe, waves="w2"):
-    """average issue cycles per VALU wave-instruction for this mix, from the probe's measurements at `waves` per SIMD"""
+def class_rate(probe, cls_name):
+    """best measured chip-wide rate (wave-instructions / s) of one class over 1..8 waves per SIMD"""
+    c = probe["classes"][cls_name]
+    return max(c[w]["wave_insts_per_s"] for w in ("w1", "w2", "w4", "w8"))
+
+
+def peak_for_mix(counts, probe):
+    """chip-wide VALU wave-instructions / s this mix could issue at if nothing but the issue port limited it:
+    total / sum(n_c / rate_c), every class priced at its best measured rate.  A v_cndmask reads the mask the v_cmp before it
+    wrote, so both are priced with the measured cmp+cndmask pair (a lone v_cndmask on a stale VCC measures 5x slower)."""
     cls = probe["classes"]
-    fallback = {"v_readlane": "v_mov_b32_dpp", "v_trans": "v_mul_lo_u32"}
-    num = den = 0.0
+    alias = {"v_readlane": "v_mov_b32_dpp", "v_trans": "v_mul_lo_u32", "v_cndmask_b32": "mix_cmp_cndmask"}
+    t = n_all = 0.0
     for c, n in counts.items():
         if not c.startswith("v_"):
             continue
-        k = c if c in cls else fallback.get(c, "v_xor_b32")
-        num += n * cls[k][waves]["issue_cycles_per_inst"]
-        den += n
-    return num / den if den else None
+        k = alias.get(c, c if c in cls else "v_xor_b32")
+        t += n / class_rate(probe, k)
+        n_all += n
+    return n_all / t if t else None
 
 
 def main():
@@ -170,8 +178,9 @@ def main():
                "hot_loop_instructions": (region[1] - region[0] + 1) if region else 0}
         if os.path.exists(a.probe):
             probe = json.load(open(a.probe))
-            for w in ("w1", "w2", "w4", "w8"):
-                ent["weighted_issue_cycles_" + w] = {"total": weighted_issue_cycles(total, probe, w), "hot_loop": weighted_issue_cycles(hot, probe, w)}
+            ent["peak_wave_insts_per_s"] = {"total": peak_for_mix(total, probe), "hot_loop": peak_for_mix(hot, probe)}
+            ent["peak_note"] = ("VALU issue peak of this instruction mix on the whole chip, from per-class rates measured by "
+                                "tools/valu_probe.hip (best of 1, 2, 4, 8 waves per SIMD)")
         out["kernels"][name] = ent
     txt = json.dumps(out, indent=1)
     if a.out:

@@ -1,30 +1,116 @@
-"""profiles/pmc_traffic.json from the outputs of tools/pmc_passes.sh (gpurun_out/pmc_<tag>_{minimax,random,mt}/): per-launch
-FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU of the lean step kernel at 65 536 lanes.  usage: python tools/make_pmc_traffic.py <tag>"""
-import collections, csv, glob, json, os, sys
+"""profiles/pmc_traffic.json and profiles/<round>/ summaries from the output of tools/profile_r02.sh.
+
+  python tools/make_pmc_traffic.py gpurun_out/r02p profiles/r02
+
+For every configuration directory (rollout_k50, rollout_k50_notraj, step) it reads
+  stats_kernel_stats.csv                      rocprofv3 --kernel-trace --stats (average duration of the dominant kernel)
+  pmc_<COUNTERS>_counter_collection.csv       separate --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU | SQ wave cycles | ...)
+and writes per-launch averages of the dominant kernel.  HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: the gfx950
+read-side correction of MI355X_MICROARCH.md applied in full, an upper bound for this mixed-width access pattern
+(profiles/README.md).  The file carries the sha256 of the kernel sources it was measured on (bench.py refuses a stale
+one) and the VALU issue peak for this kernel's instruction mix, from tools/valu_probe.py + tools/isa_mix.py.
+"""
+import collections
+import csv
+import glob
+import hashlib
+import json
+import os
+import shutil
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1]
-out = {}
-for cfg, key in (("minimax", "minimax_d3_philox"), ("random", "random_d3_philox"), ("mt", "minimax_d3_mt19937")):
-    d = os.path.join(ROOT, "gpurun_out", "pmc_%s_%s" % (tag, cfg))
-    vals = {}
-    for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
-        acc = collections.defaultdict(list)
-        for f in glob.glob(os.path.join(d, c + "*counter_collection.csv")):
-            for r in csv.DictReader(open(f)):
-                if "k_step_d3" in r["Kernel_Name"] and r["Counter_Name"] == c:
-                    acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-        if acc:
-            k = max(acc, key=lambda k: len(acc[k]))
-            vals[c] = sum(acc[k]) / len(acc[k])
-    if len(vals) < 3:
-        continue
-    N = 65536
-    out[key] = (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024
-    out[key + "_valu_wave_insts"] = vals["SQ_INSTS_VALU"]
-    out[key + "_detail"] = {"lanes": N, "FETCH_SIZE_KB_raw": vals["FETCH_SIZE"], "WRITE_SIZE_KB_raw": vals["WRITE_SIZE"],
-                            "per_lane_fetch_raw_B": vals["FETCH_SIZE"] * 1024 / N, "per_lane_write_raw_B": vals["WRITE_SIZE"] * 1024 / N,
-                            "SQ_INSTS_VALU": vals["SQ_INSTS_VALU"],
-                            "note": "per k_step_d3 launch; hbm bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 read-side correction applied in full: an upper bound for this mixed-width pattern, profiles/README.md)"}
-json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
-print(json.dumps({k: v for k, v in out.items() if not k.endswith("_detail")}, indent=1))
+sys.path.insert(0, ROOT)
+
+
+def source_hash():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ewn_gym_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def dominant(rows, want):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in rows:
+        if want in r["Kernel_Name"]:
+            acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if not acc:
+        return None, {}
+    k = max(acc, key=lambda k: sum(len(v) for v in acc[k].values()))
+    return k, {c: sum(v) / len(v) for c, v in acc[k].items()}
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    os.makedirs(dst, exist_ok=True)
+    from bench import pmc_key
+    out = {"source_hash": source_hash()}
+    mixp = os.path.join(dst, "isa_mix.json")
+    probe = os.path.join(dst, "valu_probe.json")
+    cfgs = (("rollout_k50", "k_rollout_d3", pmc_key("rollout", "minimax", 3, "philox", 5, 65536, 50, True), 50),
+            ("rollout_k50_notraj", "k_rollout_d3", pmc_key("rollout", "minimax", 3, "philox", 5, 65536, 50, False), 50),
+            ("step", "k_step_d3", pmc_key("step", "minimax", 3, "philox", 5, 65536, 1, True), 1))
+    for name, kern, key, K in cfgs:
+        d = os.path.join(src, name)
+        if not os.path.isdir(d):
+            continue
+        ent = {"lanes": 65536, "env_steps_per_launch": K}
+        st = os.path.join(d, "stats_kernel_stats.csv")
+        if os.path.exists(st):
+            for r in csv.DictReader(open(st)):
+                if kern in r["Name"]:
+                    ent["kernel"] = r["Name"]
+                    ent["rocprof_avg_us"] = float(r["AverageNs"]) / 1e3
+                    ent["rocprof_calls"] = int(r["Calls"])
+                    break
+            shutil.copy(st, os.path.join(dst, "%s_kernel_stats.csv" % name))
+        vals = {}
+        for f in glob.glob(os.path.join(d, "pmc_*_counter_collection.csv")):
+            _, v = dominant(list(csv.DictReader(open(f))), kern)
+            vals.update(v)
+            # keep only the dominant kernel's rows of each pass: the evidence, without the framework's fill kernels
+            rows = [r for r in csv.DictReader(open(f)) if kern in r["Kernel_Name"]]
+            if rows:
+                with open(os.path.join(dst, "%s_%s" % (name, os.path.basename(f))), "w", newline="") as g:
+                    w = csv.DictWriter(g, fieldnames=list(rows[0].keys()))
+                    w.writeheader()
+                    w.writerows(rows[:60])
+        for f in ("bench.json", "bench_under_rocprof.json"):
+            p = os.path.join(d, f)
+            if os.path.exists(p):
+                lines = [l for l in open(p) if l.startswith("{")]
+                if lines:
+                    open(os.path.join(dst, "%s_%s" % (name, f)), "w").write(lines[-1])
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            ent["FETCH_SIZE_KB_raw"], ent["WRITE_SIZE_KB_raw"] = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
+            ent["hbm_bytes_per_launch"] = (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024
+            ent["per_lane_step_fetch_raw_B"] = vals["FETCH_SIZE"] * 1024 / 65536 / K
+            ent["per_lane_step_write_raw_B"] = vals["WRITE_SIZE"] * 1024 / 65536 / K
+        if "SQ_INSTS_VALU" in vals:
+            ent["valu_wave_insts_per_launch"] = vals["SQ_INSTS_VALU"]
+            ent["valu_wave_insts_per_lane_step"] = vals["SQ_INSTS_VALU"] / 65536 / K
+        for c in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_LDS", "SQ_WAVES"):
+            if c in vals:
+                ent[c] = vals[c]
+        if "SQ_WAVE_CYCLES" in vals and vals["SQ_WAVE_CYCLES"]:
+            ent["wait_any_frac"] = vals.get("SQ_WAIT_ANY", 0.0) / vals["SQ_WAVE_CYCLES"]
+            ent["active_valu_frac"] = vals.get("SQ_ACTIVE_INST_VALU", 0.0) / vals["SQ_WAVE_CYCLES"]
+        out[key] = ent
+    if os.path.exists(mixp):
+        mix = json.load(open(mixp))
+        # the peak the dominant (rollout) kernel's instruction mix could issue at, chip-wide
+        for kname, kv in mix["kernels"].items():
+            if "k_rollout_d3" in kname and "peak_wave_insts_per_s" in kv:
+                out["valu_issue_peak_per_s"] = kv["peak_wave_insts_per_s"]["hot_loop"]
+                out["valu_issue_peak_source"] = "tools/isa_mix.py hot loop of %s priced with tools/valu_probe.py (profiles/r02/valu_probe.json)" % kname
+    json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+    if not os.path.exists(probe):
+        print("note: %s missing -- run tools/valu_probe.py on the GPU box and tools/isa_mix.py here" % probe, file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()
