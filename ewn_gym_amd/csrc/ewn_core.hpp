@@ -455,7 +455,7 @@ EWN_DEV int nth_set_bit(u32 m, int k)
 
 // One lane's dice stream for the duration of a kernel.
 //  kind 0 (MT19937): np.random.seed / legacy randint, bit-exact with the reference.
-//  kind 1 (Philox):  word n of an episode = philox4x32-10(ctr={n>>2, seed, 0, 'ENV1'}, key)[n&3].  A step starts on a
+//  kind 1 (Philox):  word n of an episode = philox4x32-10(ctr={n>>2, seed, wraps of the seed so far, 'ENV1'}, key)[n&3].  A step starts on a
 //                    block boundary and needs <= 3 words (opponent dice, random opponent's choice, next dice), so ONE
 //                    Philox block serves a step; bounded draws use Lemire's multiply-shift (exact: the rare rejection
 //                    re-draws); an episode's first dice is a hash of its seed, so reset() needs no second block.
@@ -480,8 +480,12 @@ struct LaneRng {
     {
         kind = kind_; seed = h.x; n = h.y; next_seed = h.z; flags = h.w; W = W_; win = win_;
         p0 = p1 = p2 = p3 = p4 = p5 = p6 = p7 = 0; pre_base = 0xFFFFFFF0u; pre_lim = 8u; q0 = q1 = q2 = q3 = 0; q_valid = false;
-        if (kind == 1) ps.init(seed, 0u, 0x454E5631u, key, n);
+        if (kind == 1) ps.init(seed, flags, 0x454E5631u, key, n); // Philox kind: the header's 4th word is the episode index's HIGH word
     }
+    // The episode seed advances by seed_stride per auto-reset and wraps after 2^32 / stride episodes of a lane (np.random.seed is
+    // 32-bit: inherent for the MT kind).  The Philox kind counts the wraps in the header's 4th word and feeds it to the counter
+    // (c2) and to every hash keyed by the episode, so a lane's dice streams do not repeat before 2^64 / stride episodes.
+    EWN_DEV u32 seed_mix() const { return kind == 1 ? seed ^ (flags * 0x9E3779B9u) : seed; }
     EWN_DEV uint4 header() const { return make_uint4(seed, kind == 1 ? ps.n : n, next_seed, flags); }
     EWN_DEV u32 draws() const { return kind == 1 ? ps.n : n; }
     EWN_DEV u32 next()
@@ -544,15 +548,15 @@ struct LaneRng {
                 if (pend) { pend->n = 2; pend->slot0 = (cur + 1u) % 3u; pend->seed0 = s2 + stride;
                             pend->slot1 = (cur + 2u) % 3u; pend->seed1 = s2 + 2u * stride; }
             }
-        } else f = 0;
-        load(kind, make_uint4(s2, 0u, s2 + stride, f), rng_win_ptr(rng, N, W, lane, RNGF_CUR(f)), W, key);
+        } else f = flags + (s2 < seed ? 1u : 0u); // Philox kind: seed + stride wrapped past 2^32 -> next high word
+        load(kind, make_uint4(s2, 0u, s2 + stride, f), rng_win_ptr(rng, N, W, lane, kind == 0 ? RNGF_CUR(f) : 0u), W, key);
         prefetch();
     }
     EWN_DEV void begin_step() { if (kind == 1) ps.n = (ps.n + 3u) & ~3u; }
     EWN_DEV int first_dice(int cube_num)
     {
         if (kind != 1) return randint(1, cube_num + 1);      // roll_dice, envs/ewn.py:90-91
-        const u32 w = fmix32(seed ^ fmix32(ps.k0 ^ 0x454E5631u) ^ (ps.k1 * 0x9E3779B1u));
+        const u32 w = fmix32(seed_mix() ^ fmix32(ps.k0 ^ 0x454E5631u) ^ (ps.k1 * 0x9E3779B1u));
         return 1 + (int)__umulhi(w, (u32)cube_num);           // bias <= cube_num / 2^32
     }
     EWN_DEV int lemire(u32 range)

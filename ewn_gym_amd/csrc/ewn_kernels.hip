@@ -244,7 +244,7 @@ __global__ __launch_bounds__(BS) void k_step(Geom g, KCfg c, KState st, const in
                         const GState<NW> cst = canonicalize<NW>(g, s);
                         encode_board<NW>(g, cst, sc.cboard + (size_t)lane * g.cells);
                         sc.cdice[lane] = (int8_t)dice;
-                        sc.obs_id[lane] = r.seed * 0x9E3779B1u + r.draws();
+                        sc.obs_id[lane] = r.seed_mix() * 0x9E3779B1u + r.draws();
                         settled = false;
                     }
                 } else if (reply) {
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(BS) void k_step(Geom g, KCfg c, KState st, const in
                     if (!(o.term && !c.autoreset)) {
                         const int n = for_each_legal<0, NW>(g, s, dice, [](int, int, int) { return true; });
                         if (n > 0) {
-                            const int pick = (int)__umulhi(agent_hash(r.seed, r.draws(), (u32)(c.lane_offset + lane), c.key), (u32)n);
+                            const int pick = (int)__umulhi(agent_hash(r.seed_mix(), r.draws(), (u32)(c.lane_offset + lane), c.key), (u32)n);
                             int i = 0;
                             for_each_legal<0, NW>(g, s, dice, [&](int flag, int, int dir) { if (i == pick) { f = flag; d = dir; } i++; return i <= pick; });
                         }

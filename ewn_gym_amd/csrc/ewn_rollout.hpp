@@ -115,7 +115,7 @@ __global__ __launch_bounds__(D3_BS) void k_rollout_d3(RollCfg c, RollBuf B)
             const u32 okm = (u32)Tb->lgn[pp & 0xFFu] | ((u32)Tb->lgn[pp >> 8] << 3);
             const int n = __popc(okm);
             if (n > 0) {
-                const u32 w = agent_hash(r.seed, r.draws(), (u32)(c.lane_offset + game), c.key);
+                const u32 w = agent_hash(r.seed_mix(), r.draws(), (u32)(c.lane_offset + game), c.key);
                 const int slot = Tb->nth[okm * 8u + __umulhi(w, (u32)n)];
                 aflag = slot < 3 ? (int)(e >> 15) : 0;
                 adir = slot < 3 ? slot : slot - 3;

@@ -745,3 +745,46 @@ def test_g9b_mcts_playout_policy_chi_square_vs_reference(ea, golden):
         c2, cells, bias = _mcts_chi2(recs, lambda i, j: int(wins[i, j]), nsim)
         assert chi2.sf(c2, cells) > 1e-3, (S, c2, cells)
         assert abs(bias) < 3.5, (S, bias)
+
+
+def test_philox_streams_do_not_repeat_when_the_seed_wraps(ea):
+    """The episode seed advances by seed_stride per auto-reset and is 32 bits wide (np.random.seed's range).  The Philox kind
+    counts the wraps in the RNG header and keys the counter and every per-episode hash with it (without it a lane
+    replays another lane's dice after 2^32 / stride episodes).  Lanes started just below 2^32 wrap within a few episodes: lock-step
+    against the oracle through the wrap (single steps, the fused RandomAgent output and K-step rollouts), and the episode after
+    the wrap must NOT be the episode a fresh engine plays from the same 32-bit seed."""
+    N = 600
+    seeds = ((1 << 32) - 1500 + np.arange(N, dtype=np.uint64) * 3).astype(np.uint32)
+    kw = dict(opponent_policy="random", rng="philox", philox_key=77, autoreset=True, seed_stride=N)
+    env = ea.VecEWN(N, want_random_action=True, **kw)
+    orc = po.OracleVecEnv(N, opponent="random", rng="philox", philox_key=77, autoreset=True, seed_stride=N)
+    env.reset(seeds=seeds)
+    orc.reset(seeds=seeds)
+    buf = env.random_action
+    acts = orc.random_actions()
+    buf.copy_(torch.from_numpy(acts))
+    for t in range(45):
+        res = [cpu(x) for x in env.step(buf)]
+        ores = orc.step(acts)
+        for a, o in zip(res, ores):
+            assert np.array_equal(a, o), t
+        acts = orc.random_actions()
+        assert np.array_equal(cpu(buf), acts), t
+    hdr = cpu(env.rng_state.view(-1)[:4 * N]).reshape(N, 4).view(np.uint32)
+    wrapped = hdr[:, 3] > 0
+    assert wrapped.sum() > N // 2                      # most lanes are past 2^32 by now
+    traj = env.alloc_rollout(20)
+    env.rollout(20, traj=traj)
+    for k in range(20):
+        a = orc.random_actions()
+        assert np.array_equal(cpu(traj["action"][k]), a), k
+        ob, od, r, te, _, _ = orc.step(a)
+        assert np.array_equal(cpu(traj["board"][k]), ob) and np.array_equal(cpu(traj["dice"][k]), od), k
+    # same 32-bit seed, different high word: a different dice stream
+    lanes = np.nonzero(wrapped)[0][:64]
+    cur_seed = cpu(env.rng_state.view(-1)[:4 * N]).reshape(N, 4).view(np.uint32)[lanes, 0]
+    # word 0 of an episode's stream is philox(ctr = {0, seed, high word, 'ENV1'}): the high word changes the block
+    from oracle.pyoracle import philox
+    key = np.array([77, 0], np.uint32)
+    differ = sum(int(not np.array_equal(philox([0, s, 0, 0x454E5631], key), philox([0, s, 1, 0x454E5631], key))) for s in cur_seed[:16])
+    assert differ == 16

@@ -51,6 +51,7 @@ def main():
     mixp = os.path.join(dst, "isa_mix.json")
     probe = os.path.join(dst, "valu_probe.json")
     cfgs = (("rollout_k50", "k_rollout_d3", pmc_key("rollout", "minimax", 3, "philox", 5, 65536, 50, True), 50),
+            ("rollout_k20", "k_rollout_d3", pmc_key("rollout", "minimax", 3, "philox", 5, 65536, 20, True), 20),
             ("rollout_k50_notraj", "k_rollout_d3", pmc_key("rollout", "minimax", 3, "philox", 5, 65536, 50, False), 50),
             ("step", "k_step_d3", pmc_key("step", "minimax", 3, "philox", 5, 65536, 1, True), 1))
     for name, kern, key, K in cfgs:

@@ -20,6 +20,7 @@ run_cfg() { # name, bench args...
   python3 $R/bench.py $COMMON "$@" > $OUT/$name/bench.json 2> $OUT/$name/bench.err
 }
 run_cfg rollout_k50 --steps-per-launch 50
+run_cfg rollout_k20 --steps-per-launch 20     # the launch shape of `bench.py --steps 20` (the driver's invocation)
 run_cfg rollout_k50_notraj --steps-per-launch 50 --no-trajectory
 run_cfg step --mode step
 echo done

@@ -1,5 +1,5 @@
 """One-off soak: lock-step HIP vs CPU oracle on many lanes and steps (all six outputs bit-exact), beyond what tests/ runs.
-usage (GPU box): python tools/soak_parity.py"""
+usage (GPU box): python tools/soak_parity.py [mcts | predict | r02]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -30,7 +30,7 @@ def run(N, steps, lo, hi, **kw):
         nterm += int(ores[3].sum())
     print("ok N=%d steps=%d slice=%d episodes=%d %r (%.1f s)" % (N, steps, hi - lo, nterm, kw, time.time() - t0), flush=True)
 
-if len(sys.argv) > 1 and sys.argv[1] == "mcts":
+if len(sys.argv) > 1:   # a named part (mcts / predict / r02)
     pass
 else:
   run(40000, 120, 1000, 3000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=5)
@@ -84,3 +84,49 @@ if len(sys.argv) > 1 and sys.argv[1] == "predict":
             assert np.array_equal(acts.cpu().numpy(), oa) and np.array_equal(bits(vals.cpu().numpy()), bits(ov)), (S, depth)
             print("ok predict S=%d depth=%d positions=%d (%.1f s)" % (S, depth, n, time.time() - t0), flush=True)
     print("predict soak passed")
+
+if len(sys.argv) > 1 and sys.argv[1] == "r02":
+    # round 2 paths: shaped env and integer heuristics on the table-driven kernel, K-step rollouts (ewn_step_k)
+    run(40000, 60, 1000, 3000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=21, shaped=True, reward=10.0,
+        illegal_move_tolerance=3, shaped_refresh_on_reset=True)
+    run(20000, 60, 0, 2000, opponent_policy="random", rng="mt19937", shaped=True, reward=10.0, illegal_move_tolerance=5)
+    run(20000, 50, 4000, 6000, opponent_policy="minimax", max_depth=3, heuristic="min_dist", rng="philox", philox_key=22)
+    run(20000, 50, 4000, 6000, opponent_policy="minimax", max_depth=4, heuristic="attk", rng="mt19937")
+    run(6000, 30, 0, 1500, opponent_policy="minimax", max_depth=5, heuristic="attk", rng="philox", philox_key=23)
+    run(10000, 40, 0, 2000, opponent_policy="minimax", max_depth=3, heuristic="min_dist", rng="philox", philox_key=24, board_size=7)
+
+    def roll(N, K, launches, lo, hi, agent="random", agent_max_depth=3, autoreset=True, **kw):
+        okw = dict(kw); opp = okw.pop("opponent_policy")
+        env = ea.VecEWN(N, opponent_policy=opp, autoreset=autoreset, seed_stride=N, **okw)
+        seeds = (np.arange(N, dtype=np.uint64) * 3 + 99).astype(np.uint32)
+        env.reset(seeds=seeds)
+        orc = po.OracleVecEnv(hi - lo, opponent=opp, autoreset=autoreset, seed_stride=N, lane_offset=lo, **okw)
+        ob, od = orc.reset(seeds=seeds[lo:hi])
+        traj = env.alloc_rollout(K)
+        frozen = np.zeros(hi - lo, bool)
+        t0 = time.time(); nterm = 0
+        for launch in range(launches):
+            env.rollout(K, agent=agent, agent_max_depth=agent_max_depth, traj=traj)
+            tj = {k: v[:, lo:hi].cpu().numpy() for k, v in traj.items()}
+            for k in range(K):
+                acts = orc.random_actions() if agent == "random" else po.predict_minimax(ob, od, agent_max_depth, "hybrid")[0]
+                live = ~frozen
+                assert np.array_equal(tj["action"][k][live], acts[live]), (kw, launch, k)
+                ob, od, r, te, tr, info = orc.step(np.where(live[:, None], acts, 0).astype(np.int8))
+                for name, o in (("board", ob), ("dice", od), ("terminated", te), ("truncated", tr), ("info", info)):
+                    assert np.array_equal(tj[name][k], o), (kw, launch, k, name)
+                assert np.array_equal(bits(tj["reward"][k]), bits(r)), (kw, launch, k)
+                nterm += int((live & (te != 0)).sum())
+                if not autoreset:
+                    frozen |= te != 0
+        print("ok rollout N=%d K=%d launches=%d slice=%d episodes=%d agent=%s %r (%.1f s)" % (N, K, launches, hi - lo, nterm, agent, kw, time.time() - t0), flush=True)
+
+    roll(65536, 50, 4, 30000, 32000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=31)
+    roll(262144, 25, 2, 200000, 201000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=32)
+    roll(20000, 40, 3, 0, 2000, opponent_policy="random", rng="philox", philox_key=33)
+    roll(20000, 30, 2, 3000, 4000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=34, board_size=7)
+    roll(4000, 20, 3, 0, 1000, opponent_policy="minimax", max_depth=4, heuristic="attk", rng="philox", philox_key=35, board_size=8)
+    roll(2048, 12, 4, 0, 1024, agent="minimax", agent_max_depth=3, autoreset=False, opponent_policy="minimax", max_depth=3, rng="mt19937")
+    roll(1024, 10, 4, 0, 512, agent="minimax", agent_max_depth=5, autoreset=False, opponent_policy="random", rng="mt19937")
+    roll(512, 10, 3, 0, 256, agent="minimax", agent_max_depth=3, autoreset=False, opponent_policy="minimax", max_depth=5, rng="philox", philox_key=36)
+    print("r02 soak passed")
