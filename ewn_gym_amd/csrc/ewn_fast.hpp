@@ -29,24 +29,28 @@
 #include "ewn_core.hpp"
 
 #define FAST_NV 1024   // distinct leaf values (incl. +-10) get ranks 1..nv in 10 bits; 0 = "none", 1023 = "no such reply"
-#define FAST_NONE 1023u // packed (cut << 10 | p2) of a cube that is not on the board
+// Ranks travel through the search as BYTE OFFSETS into val[] / val6[] (8 x rank): order and equality are those of the ranks,
+// and a value lookup needs no address arithmetic (measured round 2: every u16 / f64 table read cost one half-rate VALU shift).
+#define FAST_NONE8 (1023u * 8u)             // "no such reply": val = +inf
+#define FAST_KNONE (0x8000u | FAST_NONE8)   // key (see d3_search) of a cube that is not on the board
 
 template <int S>
 struct FastTab {
-    static constexpr int IXN = S * 8;            // index of one side's (level t, count n): t*8 + n, n <= 6
     static constexpr int CELLS = S * S;
-    uint16_t rank[IXN * IXN];                    // [ix(P side)][iy(N side)] -> rank of (0 + x) - y: 1 = lowest value (-10) ... nv
+    // one side's (level t, count n) is the 6-bit index t*8 + n (t <= 7, n <= 6); a leaf is the pair (ix of the P side, iy of the
+    // N side).  rank[(ix << 6) | iy] = 8 x the rank of (0 + x) - y among the table's distinct values: 1 = lowest ... nv = +10
+    uint16_t rank[64 * 64];
     double val[FAST_NV];                         // rank -> leaf value (ascending); val[0] = -inf (rank 0 = "none"), unused ranks = +inf
     double val6[FAST_NV];                        // rank -> value / 6.0 (IEEE quotient, host-computed)
-    uint16_t lutx[72];                           // clz(P mask) -> t*8*IXN   (entry for an empty mask: 0)
-    uint16_t luty[72];                           // clz(N mask) -> t*8
+    uint8_t lvl_guard[8];                        // lvl[-1]: v_ffbh_u32 answers -1 for an empty 32-bit mask; level 0 + count 0 = the "-10" row
+    uint8_t lvl[72];                             // clz(mask) -> level << 3 (entry for an empty mask: 0)
     uint8_t ri[64];                              // canonical row-major cell -> ring index
     // position bytes (ewn_step_d3.hpp: one byte per cube = its ring index, bit 6 set once it is off the board) index the
     // next five tables directly, so they have 128 entries: 64..127 = "no such cube" -> off board / no legal direction
     uint8_t nbp[3][128];                         // mover   (TOP_LEFT):     ring index -> destination ring index, 255 = off board
     uint8_t nbn[3][128];                         // replier (BOTTOM_RIGHT): ring index -> destination ring index, 255 = off board
     uint8_t lgp[128], lgn[128];                  // ring index -> legal directions of a TOP_LEFT / BOTTOM_RIGHT cube there (bits 0..2)
-    int32_t nv, ri_origin, pad0, pad1;           // number of ranks; ring index of cell (0,0)
+    int32_t nv, ri_origin, m10, pad1;            // number of ranks (= rank of +10); ring index of cell (0,0); rank of -10
     // for the fused step kernel (ewn_step_d3.hpp), which keeps the game in canonical ring space:
     uint8_t real_of_ring[64];                    // ring index -> REAL row-major cell (canonical cell = S*S-1 - real cell)
     uint64_t init_P, init_N, init_posP, init_posN; // the start position (envs/ewn.py:94-107): opponent = P side, agent = N side
@@ -92,6 +96,17 @@ EWN_DEV int clz_nz(u64 m)
 }
 EWN_DEV int popc_m(u32 m) { return __popc(m); }
 EWN_DEV int popc_m(u64 m) { return __popcll(m); }
+// index into FastTab::lvl: the raw v_ffbh of a 32-bit mask (-1 for an empty one: lvl[-1] is the guard byte, inside the table
+// image; an out-of-range LDS read would answer 0 as well), the clamped count of a 64-bit one
+EWN_DEV int lvl_index(u32 m) { return clz_nz(m); }
+EWN_DEV int lvl_index(u64 m) { return clz_m(m); }
+// one side's 6-bit (level, count) index: one byte read + v_bcnt_u32_b32 with its accumulate operand
+template <int S> EWN_DEV u32 ft_side(const FastTab<S> *Tb, typename MaskOf<S>::type m) { return (u32)Tb->lvl[lvl_index(m)] + (u32)popc_m(m); }
+// byte address of a leaf's entry inside rank[]
+EWN_DEV u32 ft_addr(u32 ix, u32 iy) { return (ix << 7) | (iy << 1); }
+template <int S> EWN_DEV u32 ft_rank8(const FastTab<S> *Tb, u32 addr) { return *(const uint16_t *)((const char *)Tb->rank + addr); }
+template <int S> EWN_DEV double ft_val(const FastTab<S> *Tb, u32 r8) { return *(const double *)((const char *)Tb->val + r8); }
+template <int S> EWN_DEV double ft_val6(const FastTab<S> *Tb, u32 r8) { return *(const double *)((const char *)Tb->val6 + r8); }
 
 // ---------------------------------------------------------------- host: table construction
 #include <algorithm>
@@ -105,7 +120,7 @@ EWN_DEV int popc_m(u64 m) { return __popcll(m); }
 template <int S>
 static int build_fast_tables(FastTab<S> *T, int variant = 0, int heur = 0)
 {
-    constexpr int IXN = FastTab<S>::IXN;
+    constexpr int IXN = 64;
     memset(T, 0, sizeof(*T));
     // ring order: ascending level t = min(row, col); (0,0) first, (S-1,S-1) last
     int ring_of_rm[64], rm_of_ring[64], n = 0;
@@ -169,8 +184,7 @@ static int build_fast_tables(FastTab<S> *T, int variant = 0, int heur = 0)
     for (int z = 0; z <= W; z++) {
         const int h = W - 1 - z; // highest set bit
         const int t = (z == W || h >= S * S) ? 0 : level_of_ring[h];
-        T->lutx[z] = (uint16_t)(t * 8 * IXN);
-        T->luty[z] = (uint16_t)(t * 8);
+        T->lvl[z] = (uint8_t)(t << 3);
     }
     // leaf values: score = 0; score += (L - mdP) * (1 / nP); score -= (L - mdN) * (1 / nN)   (envs/minimax_ewn.py:79-82)
     // with L = S, md = S - 1 - t.  volatile keeps every rounding step a separate fp64 operation.
@@ -197,6 +211,7 @@ static int build_fast_tables(FastTab<S> *T, int variant = 0, int heur = 0)
     all.erase(std::unique(all.begin(), all.end()), all.end());
     if ((int)all.size() > FAST_NV - 3) return -1;
     T->nv = (int)all.size();
+    T->m10 = (int)(1 + (std::lower_bound(all.begin(), all.end(), -10.0) - all.begin()));
     for (int i = 0; i < FAST_NV; i++) {
         const double v = i == 0 ? -__builtin_inf() : (i <= T->nv ? all[i - 1] : __builtin_inf()); // unused ranks compare above every alpha
         volatile double q = v / 6.0;
@@ -206,10 +221,10 @@ static int build_fast_tables(FastTab<S> *T, int variant = 0, int heur = 0)
     const uint16_t m10 = (uint16_t)(1 + (std::lower_bound(all.begin(), all.end(), -10.0) - all.begin()));
     for (int ix = 0; ix < IXN; ix++)
         for (int iy = 0; iy < IXN; iy++) {
-            const bool used = (ix % 8) >= 1 && (ix % 8) <= 6 && (iy % 8) >= 1 && (iy % 8) <= 6;
+            const bool used = (ix % 8) >= 1 && (ix % 8) <= 6 && (iy % 8) >= 1 && (iy % 8) <= 6 && ix / 8 < S && iy / 8 < S;
             // a slot no position maps to (count 0 = the side has lost its last cube, envs/minimax_ewn.py:45-47) answers -10
-            T->rank[ix * IXN + iy] = used ? (uint16_t)(1 + (std::lower_bound(all.begin(), all.end(), e[(size_t)ix * IXN + iy]) - all.begin())) : m10;
+            T->rank[ix * IXN + iy] = (uint16_t)(8 * (used ? (uint16_t)(1 + (std::lower_bound(all.begin(), all.end(), e[(size_t)ix * IXN + iy]) - all.begin())) : m10));
         }
-    T->rank[0] = 1023; T->rank[1] = m10; // unused (level 0, count 0) slots that d3_search's leaf index is steered to: "no such reply", -10
+    T->rank[0] = (uint16_t)FAST_NONE8; T->rank[1] = (uint16_t)(8 * m10); // unused (level 0, count 0) slots that d3_search's leaf index is steered to: "no such reply", -10
     return 0;
 }

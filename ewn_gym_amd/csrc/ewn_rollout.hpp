@@ -17,6 +17,14 @@
 #pragma once
 #include "ewn_step_d3.hpp"
 
+// Diagnostic build only (tools/rollout_stamps.py, -DEWN_ROLLOUT_STAMPS): s_memtime at the phase boundaries of a step, summed over the
+// K steps of a launch per wave and written over the (then meaningless) return_sum buffer.  Never defined in the shipped library.
+#ifdef EWN_ROLLOUT_STAMPS
+#define RSTAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_acc[i] += t_ - st_prev; st_prev = t_; } while (0)
+#else
+#define RSTAMP(i) do { } while (0)
+#endif
+
 struct RollCfg {
     int N, autoreset, lane_offset, depth, agent_depth, K;  // depth / agent_depth: max_depth of the opponent's / the agent's search
     u32 seed_stride, W;
@@ -63,7 +71,14 @@ __global__ __launch_bounds__(D3_BS) void k_rollout_d3(RollCfg c, RollBuf B)
 {
     constexpr int CELLS = S * S, GPB = D3_BS / T; // games per block
     constexpr int TS = T > 2 ? 2 : T;             // lanes per game the depth-5 search can use
-    extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+    // LDS: boards | table image(s) | 16 bytes per game of decode scratch.  With the RandomAgent agent (one image) the block is a
+    // STATIC array: its address is then a compile-time constant that folds into the offset field of every ds_read, where the
+    // dynamic-LDS base is a link-time symbol the compiler adds with one VALU instruction in front of every table read (43 per
+    // root of the search).  Two images (minimax agents of another depth class) can exceed the 64 KB static limit: dynamic.
+    extern __shared__ __attribute__((aligned(16))) int8_t lds_dyn[];
+    constexpr int LDS_STATIC = AGENT == 0 ? ((GPB * CELLS + 15) & ~15) + FAST_TAB_BYTES(S) + GPB * 16 : 16;
+    __shared__ __attribute__((aligned(16))) int8_t lds_st[LDS_STATIC];
+    int8_t *lds = AGENT == 0 ? lds_st : lds_dyn;
     int8_t *tb = lds + ((GPB * CELLS + 15) & ~15);
     tables_to_lds<FAST_TAB_BYTES(S)>(tb, (const int8_t *)B.tables); // LDS-DMA, waited for at the barrier
     const FastTab<S> *Tb = (const FastTab<S> *)tb;
@@ -101,6 +116,11 @@ __global__ __launch_bounds__(D3_BS) void k_rollout_d3(RollCfg c, RollBuf B)
     double ret_acc = 0.0;
     int n_steps = 0, n_eps = 0, n_wins = 0;
 
+#ifdef EWN_ROLLOUT_STAMPS
+    unsigned long long st_acc[6] = { 0, 0, 0, 0, 0, 0 }, st_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev) :: "memory");
+    const unsigned long long st_begin = st_prev;
+#endif
     #pragma unroll 1
     for (int kstep = 0; kstep < c.K; kstep++) {
         const bool active = live && !frozen;
@@ -131,6 +151,7 @@ __global__ __launch_bounds__(D3_BS) void k_rollout_d3(RollCfg c, RollBuf B)
             r.begin_step();
             if constexpr (RNGK == 1) r.ps.prime();
         }
+        RSTAMP(0); // agent's action + RNG block
         bool reply = false;
         if (active) {
             // agent half, envs/ewn.py:438-458
@@ -143,10 +164,12 @@ __global__ __launch_bounds__(D3_BS) void k_rollout_d3(RollCfg c, RollBuf B)
                 else { dice = r.randint(1, 7); reply = true; }
             }
         }
+        RSTAMP(1); // agent half
         // the opponent's search: run by every lane (lanes without a pending reply compute on a harmless state)
         int oflag = 0, odir = 0;
         if constexpr (OPP == 0) d3_search<S, T>(Tb, s, dice, sub, c.depth, oflag, odir);
         if constexpr (OPP == 2) d5_search<S, TS>(Tb, s, dice, T > 2 ? (sub & 1) : sub, oflag, odir);
+        RSTAMP(2); // search
         if (reply) {
             // opponent half, envs/ewn.py:464-486
             const u32 e = pk_sel<S>(Tb, s.posP, dice);
@@ -173,6 +196,7 @@ __global__ __launch_bounds__(D3_BS) void k_rollout_d3(RollCfg c, RollBuf B)
                 } else frozen = true;
             }
         }
+        RSTAMP(3); // opponent half + bookkeeping + auto-reset
         // ---- this step's row of the trajectory
         if (writer) {
             const size_t o = (size_t)kstep * c.N + game;
@@ -187,31 +211,48 @@ __global__ __launch_bounds__(D3_BS) void k_rollout_d3(RollCfg c, RollBuf B)
             // A wave's games are one contiguous, 16-byte aligned span of LDS (64 / T games x S*S bytes): the wave copies its own
             // span out and no block-wide barrier is needed, so the waves of a block drift apart freely (LDS operations of one
             // wave execute in program order).  The last, partial block of the grid and an unaligned row take the block copy.
-            if (live) d3_encode<S, T>(Tb, s, sub, mine);
             int8_t *row = B.t_board + ((size_t)kstep * c.N + g0) * CELLS;
             constexpr int WB = (64 / T) * CELLS;       // bytes per wave
             static_assert(WB % 16 == 0, "a wave's span of boards is a whole number of 16-byte pieces");
             if (ng == GPB && (((uintptr_t)row) & 15) == 0) {
-                __builtin_amdgcn_wave_barrier();
+                // zero the wave's span with 16-byte stores (one instruction for the wave instead of S*S / T byte stores per
+                // lane), drop the <= 12 cube bytes of every game in, copy the span out
                 const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
-                const uint4 *src = (const uint4 *)(lds + wv * WB);
+                uint4 *span = (uint4 *)(lds + wv * WB);
+                __builtin_amdgcn_wave_barrier();
+                #pragma unroll
+                for (int i = 0; i < (WB / 16 + 63) / 64; i++) { const int j = i * 64 + ln; if (j < WB / 16) span[j] = make_uint4(0u, 0u, 0u, 0u); }
+                __builtin_amdgcn_wave_barrier();
+                d3_encode_cubes<S, T>(Tb, s, sub, mine);
+                __builtin_amdgcn_wave_barrier();
                 uint4 *dst = (uint4 *)(row + wv * WB);
                 #pragma unroll
-                for (int i = 0; i < (WB / 16 + 63) / 64; i++) { const int j = i * 64 + ln; if (j < WB / 16) dst[j] = src[j]; }
+                for (int i = 0; i < (WB / 16 + 63) / 64; i++) { const int j = i * 64 + ln; if (j < WB / 16) dst[j] = span[j]; }
                 __builtin_amdgcn_wave_barrier();
             } else {
+                if (live) d3_encode<S, T>(Tb, s, sub, mine);
                 __syncthreads();
                 block_copy_out(row, lds, ng * CELLS);
                 __syncthreads();
             }
         }
+        RSTAMP(4); // trajectory row
     }
+#ifdef EWN_ROLLOUT_STAMPS
+    if (B.ret_sum && (threadIdx.x & 63) == 0) {
+        unsigned long long *o = (unsigned long long *)B.ret_sum + (size_t)(blockIdx.x * (D3_BS / 64) + (threadIdx.x >> 6)) * 8;
+        for (int i = 0; i < 6; i++) o[i] = st_acc[i];
+        o[6] = st_begin; o[7] = st_prev;
+    }
+#endif
     // ---- the state goes back to HBM once
     if (live) d3_encode<S, T>(Tb, s, sub, mine);
     if (writer) {
         if (!frozen0) { *rng_hdr_ptr(B.rng, game) = r.header(); B.dice[game] = (int8_t)dice; }
         B.done[game] = frozen ? 1 : 0;
+#ifndef EWN_ROLLOUT_STAMPS
         if (B.ret_sum) B.ret_sum[game] += ret_acc;
+#endif
         if (B.n_steps) B.n_steps[game] += n_steps;
         if (B.n_episodes) B.n_episodes[game] += n_eps;
         if (B.n_wins) B.n_wins[game] += n_wins;

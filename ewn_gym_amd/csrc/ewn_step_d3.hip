@@ -27,7 +27,7 @@ int ewn_launch_step_d3(const ewn_config *cfg, const Geom &g, const KCfg &k, cons
     const size_t need_refill = fused_refill ? (size_t)(k.W + 1) * 65 * 4 : 0;
 #define D3_LDS(SS) (l3 + FAST_TAB_BYTES(SS) > need_refill ? l3 + FAST_TAB_BYTES(SS) : need_refill)
 #define D3_LAUNCH(SS, TT, OO) do { if (k.rng_kind == 0) k_step_d3<SS, TT, OO, 0><<<grid, D3_BS, D3_LDS(SS), s>>>(dc, db); \
-                                   else k_step_d3<SS, TT, OO, 1><<<grid, D3_BS, D3_LDS(SS), s>>>(dc, db); } while (0)
+                                   else k_step_d3<SS, TT, OO, 1><<<grid, D3_BS, d3_lds_static<SS, TT, 1>() ? 0 : D3_LDS(SS), s>>>(dc, db); } while (0)
 #define D3_BY_T(SS) do { if (lean_random) D3_LAUNCH(SS, 1, 1); else if (cfg->max_depth > 4) { if (T == 2) D3_LAUNCH(SS, 2, 2); else D3_LAUNCH(SS, 1, 2); } else if (T == 1) D3_LAUNCH(SS, 1, 0); else if (T == 2) D3_LAUNCH(SS, 2, 0); else D3_LAUNCH(SS, 4, 0); } while (0)
     switch (g.S) {
     case 5: D3_BY_T(5); break;

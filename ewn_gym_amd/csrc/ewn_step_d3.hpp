@@ -113,10 +113,9 @@ __device__ __forceinline__ double d5_search(const FastTab<S> *Tb, const RState<S
 {
     static_assert(T == 1 || T == 2, "the six dice of the inner chance node are split over one or two lanes");
     typedef typename MaskOf<S>::type M;
-    constexpr int IXN = FastTab<S>::IXN;
     const M one = 1;
     const double inf = __builtin_inf();
-    const u32 rank10 = (u32)Tb->nv; // +10 is the largest value of the table
+    const u32 rank10 = 8u * (u32)Tb->nv; // +10 is the largest value of the table (ranks travel as byte offsets, ewn_fast.hpp)
     double best = -inf, alpha = -inf;
     bflag = 0; bdir = 0;
     const u32 e0 = pk_sel<S>(Tb, c.posP, dice), pp0 = pk_pair(c.posP, e0);
@@ -167,16 +166,16 @@ __device__ __forceinline__ double d5_search(const FastTab<S> *Tb, const RState<S
                                 const M bd = ex[m] ? (one << (dp & 63)) : (M)0;
                                 const M P3 = (s2.P & ~(one << (mb & 63))) | bd, N3 = s2.N & ~bd;
                                 won[m] = dp == FastTab<S>::CELLS - 1 || N3 == 0;          // evaluate() of a won position: +10
-                                lx[m] = Tb->lutx[clz_m(P3)] + popc_m(P3) * IXN;
-                                ly[m] = Tb->luty[clz_m(N3)] + popc_m(N3);
+                                lx[m] = ft_side<S>(Tb, P3);
+                                ly[m] = ft_side<S>(Tb, N3);
                             }
                             __builtin_amdgcn_sched_barrier(0);
                             #pragma unroll
-                            for (int m = 0; m < 6; m++) lr[m] = Tb->rank[lx[m] + ly[m]];
+                            for (int m = 0; m < 6; m++) lr[m] = ft_rank8<S>(Tb, ft_addr(lx[m], ly[m]));
                             __builtin_amdgcn_sched_barrier(0);
                             double lv[6];
                             #pragma unroll
-                            for (int m = 0; m < 6; m++) { lr[m] = won[m] ? rank10 : lr[m]; lv[m] = Tb->val[lr[m]]; }
+                            for (int m = 0; m < 6; m++) { lr[m] = won[m] ? rank10 : lr[m]; lv[m] = ft_val<S>(Tb, lr[m]); }
                             __builtin_amdgcn_sched_barrier(0);
                             u32 bestr = 0;                   // rank 0 = -inf
                             double bestv = -inf;
@@ -198,7 +197,7 @@ __device__ __forceinline__ double d5_search(const FastTab<S> *Tb, const RState<S
                         }
                         double q6[6];
                         #pragma unroll
-                        for (int d = 0; d < 6; d++) q6[d] = Tb->val6[bd6[d]];
+                        for (int d = 0; d < 6; d++) q6[d] = ft_val6<S>(Tb, bd6[d]);
                         #pragma unroll
                         for (int d = 0; d < 6; d++) val = val + q6[d];   // expected_val += val / 6 in dice order
                     }
@@ -215,13 +214,43 @@ __device__ __forceinline__ double d5_search(const FastTab<S> *Tb, const RState<S
     return best;
 }
 
-// Depth-3 hybrid search in ring space, shared by T lanes (sub = my index in the group).
+// element `sub + T * i` of a six-element array held identically by the T lanes of a group, for the lane with index `sub`
+template <int T> EWN_DEV u32 own_of(const u32 (&v)[6], int i, int sub)
+{
+    if constexpr (T == 1) return v[i];
+    else if constexpr (T == 2) return sub ? v[2 * i + 1] : v[2 * i];
+    else {
+        if (i == 0) { const u32 lo = (sub & 1) ? v[1] : v[0], hi = (sub & 1) ? v[3] : v[2]; return (sub & 2) ? hi : lo; }
+        return (sub & 1) ? v[5] : v[4];   // lanes 2 and 3 have no second dice (6 % 4 = 2): their value is never used
+    }
+}
+
+// every lane of a group of T gets all T lanes' `mine`: out[T * i + j] = lane j's value
+template <int T> EWN_DEV void publish(u32 mine, int i, u32 (&out)[6])
+{
+    if constexpr (T == 1) out[i] = mine;
+    else if constexpr (T == 2) { out[2 * i] = dpp_u32<Bcast<2, 0>::CTRL>(mine); out[2 * i + 1] = dpp_u32<Bcast<2, 1>::CTRL>(mine); }
+    else {
+        if (i == 0) { out[0] = dpp_u32<Bcast<4, 0>::CTRL>(mine); out[1] = dpp_u32<Bcast<4, 1>::CTRL>(mine);
+                      out[2] = dpp_u32<Bcast<4, 2>::CTRL>(mine); out[3] = dpp_u32<Bcast<4, 3>::CTRL>(mine); }
+        else { out[4] = dpp_u32<Bcast<4, 0>::CTRL>(mine); out[5] = dpp_u32<Bcast<4, 1>::CTRL>(mine); }
+    }
+}
+
+// Depth-3 search in ring space ('hybrid', 'min_dist' or 'attk' by table image), shared by T lanes (sub = my index in the group).
 // Every lane of the group returns the same (value, action).
+//
+// Instruction budget (round 2, measured with tools/valu_probe.hip: only and/or/xor/add/mov issue at the full rate, everything
+// else -- shifts by a variable, v_cndmask, v_bcnt, v_ffbh, DPP, compares -- at about half of it, so the loop is written to need
+// few instructions of the second kind): per leaf two mask operations, two v_ffbh, two byte reads of the level table (no address
+// arithmetic), two v_bcnt with the level as their accumulate operand, a shift + v_lshl_or for the byte address of the rank, one
+// v_and_or for the root-invariant exceptions; ranks travel as byte offsets (8 x rank) so that value reads need no shift either;
+// a cube's result is ONE 16-bit key (the cut-off value if its replies cut, else 0x8000 | minimum) so that the pair selection per
+// dice is a compare, a min and a select; the lanes exchange keys and chosen ranks, never doubles.
 template <int S, int T>
 __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S> &c, int dice, int sub, int depth, int &bflag, int &bdir)
 {
     typedef typename MaskOf<S>::type M;
-    constexpr int IXN = FastTab<S>::IXN;
     constexpr int KPT = 6 / T + (6 % T ? 1 : 0); // replier cubes / dice values per lane: k = sub + T*i
     const M one = 1;
 
@@ -249,8 +278,8 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
             const M P1 = (c.P & ~(one << rp)) | bd;
             const M N1 = c.N & ~bd;
             const bool term = dest == FastTab<S>::CELLS - 1 || N1 == 0; // win(B1): value 10 at any depth
-            const u32 rk = Tb->rank[Tb->lutx[clz_m(P1)] + popc_m(P1) * IXN + Tb->luty[clz_m(N1)] + popc_m(N1)];
-            const double e1 = Tb->val[rk], e6 = Tb->val6[rk];
+            const u32 rk = ft_rank8<S>(Tb, ft_addr(ft_side<S>(Tb, P1), ft_side<S>(Tb, N1)));
+            const double e1 = ft_val<S>(Tb, rk), e6 = ft_val6<S>(Tb, rk);
             double v = 0.0;
             #pragma unroll
             for (int d = 0; d < 6; d++) v = v + e6;
@@ -263,8 +292,8 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
     // my share of the replier's (cube, dir) moves; they never change during the search
     M rset[KPT][3], rclr[KPT];
     int rnk[KPT];
-    // per reply, root-invariant: rank index = ((ix + iy) & keep) | fixed.  An illegal reply reads rank[0] = 1023 ("no such
-    // reply"), a reply onto the origin rank[1] = 1 (-10, envs/minimax_ewn.py:45-47).  The exceptions steer the INDEX instead
+    // per reply, root-invariant: byte address of the rank = (address & keep) | fixed.  An illegal reply reads rank[0] ("no such
+    // reply", +inf), a reply onto the origin rank[1] (-10, envs/minimax_ewn.py:45-47).  The exceptions steer the ADDRESS instead
     // of selecting the loaded value: a select on a loaded value makes the compiler branch around the LDS reads.
     u32 keep[KPT][3], fixed[KPT][3];
     u32 mine_alive = 0;
@@ -282,11 +311,11 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
             rset[i][d] = ok ? (one << dn) : (M)0;
             const bool home = ok && dn == Tb->ri_origin;
             keep[i][d] = (ok && !home) ? ~0u : 0u;
-            fixed[i][d] = home ? 1u : 0u;
+            fixed[i][d] = home ? 2u : 0u;
         }
     }
 
-    // a real loop, not unrolled: the body is ~450 instructions and six copies of it (plus the rest of the
+    // a real loop, not unrolled: the body is ~300 instructions and six copies of it (plus the rest of the
     // kernel) do not fit the instruction cache shared by two CUs
     #pragma unroll 1
     for (int r = 0; r < 6; r++) {
@@ -301,30 +330,32 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
 
         // Four stages, each issuing ALL its LDS reads before the next one consumes them (sched_barrier keeps the compiler from
         // re-serialising them into one round trip per leaf, which is what the register-pressure-driven schedule does):
-        // level tables -> ranks -> values of the three prefix minima -> cut.
+        // levels -> ranks -> values of the three prefix minima -> cut.
         u32 tr[6];
-        constexpr int CH = KPT > 3 ? 3 : KPT; // cubes staged together: 9 leaves in flight; more only costs registers (T = 1: 186 VGPRs)
+        constexpr int CH = KPT > 3 ? 3 : KPT; // cubes staged together: 9 leaves in flight; more only costs registers
         #pragma unroll
         for (int i0 = 0; i0 < KPT; i0 += CH) {
-            u32 lx[CH][3], ly[CH][3], am[CH], a[CH][3];
+            M P2[CH][3], N2[CH][3];
+            u32 lp[CH][3], ln[CH][3], a[CH][3];
             #pragma unroll
             for (int ii = 0; ii < CH; ii++) {
-                const int i = i0 + ii;
-                am[ii] = (((mine_alive >> i) & 1u) && rnk[i] != dest) ? ~0u : 0u; // my cube is still there after the root move
-                const M Nk = N1 & rclr[i];
+                const M Nk = N1 & rclr[i0 + ii];
                 #pragma unroll
                 for (int d = 0; d < 3; d++) {
-                    const M N2 = Nk | rset[i][d];
-                    const M P2 = P1 & ~rset[i][d];
-                    lx[ii][d] = Tb->lutx[clz_m(P2)] + popc_m(P2) * IXN; // P2 == 0 (last cube captured): row 0 of rank[] holds 1 (-10)
-                    ly[ii][d] = Tb->luty[clz_nz(N2)] + popc_m(N2);       // N2 holds the moved cube unless the reply is absent (index masked)
+                    N2[ii][d] = Nk | rset[i0 + ii][d];
+                    P2[ii][d] = P1 & ~rset[i0 + ii][d];
+                    lp[ii][d] = Tb->lvl[lvl_index(P2[ii][d])]; // P2 == 0 (last cube captured): level 0 + count 0 = a row of -10
+                    ln[ii][d] = Tb->lvl[lvl_index(N2[ii][d])]; // N2 holds the moved cube unless the reply is absent (address masked)
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
             #pragma unroll
             for (int ii = 0; ii < CH; ii++) {
                 #pragma unroll
-                for (int d = 0; d < 3; d++) a[ii][d] = Tb->rank[(((lx[ii][d] + ly[ii][d]) & keep[i0 + ii][d]) | fixed[i0 + ii][d]) & am[ii]];
+                for (int d = 0; d < 3; d++) {
+                    const u32 ix = lp[ii][d] + (u32)popc_m(P2[ii][d]), iy = ln[ii][d] + (u32)popc_m(N2[ii][d]);
+                    a[ii][d] = ft_rank8<S>(Tb, (ft_addr(ix, iy) & keep[i0 + ii][d]) | fixed[i0 + ii][d]);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             u32 p1[CH], p2[CH];
@@ -332,70 +363,53 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
             #pragma unroll
             for (int ii = 0; ii < CH; ii++) {
                 p1[ii] = min(a[ii][0], a[ii][1]); p2[ii] = min(p1[ii], a[ii][2]);
-                va[ii] = Tb->val[a[ii][0]]; v1[ii] = Tb->val[p1[ii]]; v2[ii] = Tb->val[p2[ii]]; // val[1023] = +inf: an absent reply never cuts
+                va[ii] = ft_val<S>(Tb, a[ii][0]); v1[ii] = ft_val<S>(Tb, p1[ii]); v2[ii] = ft_val<S>(Tb, p2[ii]); // +inf for "no such reply"
             }
             __builtin_amdgcn_sched_barrier(0);
             #pragma unroll
             for (int ii = 0; ii < CH; ii++) {
                 const int i = i0 + ii;
-                // per cube: full minimum p2 and `cut` = the value at which the reference's reply loop would stop inside this
-                // cube's replies (`worst <= alpha`, minimax.py:59-61; alpha = best so far), 0 if it would not.  The running
-                // minimum along a cube's replies is non-increasing, so the first one <= alpha is the largest one <= alpha.
-                u32 cut = va[ii] <= best ? a[ii][0] : 0u;
-                cut = max(cut, v1[ii] <= best ? p1[ii] : 0u);
-                cut = max(cut, v2[ii] <= best ? p2[ii] : 0u);
-                const u32 mine = p2[ii] | (cut << 10);             // a cube that is off the board: p2 = 1023, cut = 0 -> FAST_NONE
-                // publish to the group: after this every lane holds tr[k] for all six cubes (cube k = j + T*i lives in lane j)
-                if constexpr (T == 1) tr[i] = mine;
-                else if constexpr (T == 2) { tr[2 * i] = dpp_u32<Bcast<2, 0>::CTRL>(mine); tr[2 * i + 1] = dpp_u32<Bcast<2, 1>::CTRL>(mine); }
-                else {
-                    if (i == 0) { tr[0] = dpp_u32<Bcast<4, 0>::CTRL>(mine); tr[1] = dpp_u32<Bcast<4, 1>::CTRL>(mine);
-                                  tr[2] = dpp_u32<Bcast<4, 2>::CTRL>(mine); tr[3] = dpp_u32<Bcast<4, 3>::CTRL>(mine); }
-                    else { tr[4] = dpp_u32<Bcast<4, 0>::CTRL>(mine); tr[5] = dpp_u32<Bcast<4, 1>::CTRL>(mine); }
-                }
+                // per cube: `cut` = the value at which the reference's reply loop would stop inside this cube's replies
+                // (`worst <= alpha`, minimax.py:59-61; alpha = best so far), 0 if it would not.  The running minimum along a
+                // cube's replies is non-increasing (a0 >= p1 >= p2), so the loop stops at the first of them that is <= alpha.
+                // (three independent selects, last one wins: written as a nested conditional the compiler branches on it)
+                // The cube's key: its cut value if it cuts, else 0x8000 | its minimum.  A cube that is off the board (or was just
+                // captured by the root move) reads garbage leaves above: its key is forced to "no such cube" here.
+                u32 key = 0x8000u | p2[ii];
+                key = v2[ii] <= best ? p2[ii] : key;
+                key = v1[ii] <= best ? p1[ii] : key;
+                key = va[ii] <= best ? a[ii][0] : key;
+                const bool there = ((mine_alive >> i) & 1u) && rnk[i] != dest;
+                key = there ? key : FAST_KNONE;
+                publish<T>(key, i, tr); // after this every lane holds tr[k] for all six cubes (cube k = j + T*i lives in lane j)
             }
         }
-        // which cubes a dice value selects (find_near_cube): carry the nearest on-board cube's data along
+        // which cubes a dice value selects (find_near_cube): carry the nearest on-board cube's key along
         u32 upT[6], downT[6];
         {
-            u32 cur = FAST_NONE;
+            u32 cur = FAST_KNONE;
             #pragma unroll
-            for (int d = 5; d >= 0; d--) { upT[d] = cur; cur = tr[d] != FAST_NONE ? tr[d] : cur; }
-            cur = FAST_NONE;
+            for (int d = 5; d >= 0; d--) { upT[d] = cur; cur = tr[d] != FAST_KNONE ? tr[d] : cur; }
+            cur = FAST_KNONE;
             #pragma unroll
-            for (int d = 0; d < 6; d++) { downT[d] = cur; cur = tr[d] != FAST_NONE ? tr[d] : cur; }
+            for (int d = 0; d < 6; d++) { downT[d] = cur; cur = tr[d] != FAST_KNONE ? tr[d] : cur; }
         }
         // my share of the six chance branches: dice index d = sub + T*i.  Reply order is the larger-neighbour cube F, then
-        // the smaller-neighbour cube G (get_legal_actions): the loop stops in F if F cuts, else in G if G cuts, else
-        // it returns the minimum over both.
-        double q[6];
+        // the smaller-neighbour cube G (get_legal_actions): the loop stops in F if F cuts (key < 0x8000: the result is F's cut
+        // value whatever G is), else in G if G cuts, else it returns the minimum over both -- min(F, G) & 0x7fff in either case.
+        u32 wq[6];
         #pragma unroll
         for (int i = 0; i < KPT; i++) {
-            u32 F = FAST_NONE, G = FAST_NONE;
-            #pragma unroll
-            for (int j = 0; j < T; j++) {
-                const int d = T * i + j;
-                if (d < 6) {
-                    const bool exact = tr[d] != FAST_NONE, up = upT[d] != FAST_NONE;
-                    const u32 Fd = exact ? tr[d] : (up ? upT[d] : downT[d]);
-                    const u32 Gd = (!exact && up) ? downT[d] : FAST_NONE;
-                    F = (T == 1 || sub == j) ? Fd : F; G = (T == 1 || sub == j) ? Gd : G;
-                }
-            }
-            const u32 cutF = F >> 10, cutG = G >> 10;
-            const u32 w = cutF ? cutF : (cutG ? cutG : min(F & 1023u, G & 1023u));
-            const double mine = Tb->val6[w];
-            if constexpr (T == 1) q[i] = mine;
-            else if constexpr (T == 2) { q[2 * i] = dpp_f64<Bcast<2, 0>::CTRL>(mine); q[2 * i + 1] = dpp_f64<Bcast<2, 1>::CTRL>(mine); }
-            else {
-                if (i == 0) { q[0] = dpp_f64<Bcast<4, 0>::CTRL>(mine); q[1] = dpp_f64<Bcast<4, 1>::CTRL>(mine);
-                              q[2] = dpp_f64<Bcast<4, 2>::CTRL>(mine); q[3] = dpp_f64<Bcast<4, 3>::CTRL>(mine); }
-                else { q[4] = dpp_f64<Bcast<4, 0>::CTRL>(mine); q[5] = dpp_f64<Bcast<4, 1>::CTRL>(mine); }
-            }
+            const u32 e = own_of<T>(tr, i, sub), u = own_of<T>(upT, i, sub), dn = own_of<T>(downT, i, sub);
+            const bool exact = e != FAST_KNONE, up = u != FAST_KNONE;
+            const u32 F = exact ? e : (up ? u : dn);
+            const u32 G = (!exact && up) ? dn : FAST_KNONE;
+            const u32 w = F < 0x8000u ? F : (min(F, G) & 0x7FFFu);
+            publish<T>(w, i, wq);
         }
         double v = 0.0;
         #pragma unroll
-        for (int d = 0; d < 6; d++) v = v + q[d]; // expected_val += val / 6 in dice order, minimax.py:72
+        for (int d = 0; d < 6; d++) v = v + ft_val6<S>(Tb, wq[d]); // expected_val += val / 6 in dice order, minimax.py:72
         v = term ? 10.0 : v;
         if (valid && v > best) { best = v; bflag = slot == 0 ? flag0 : 0; bdir = dir; }
     }
@@ -466,6 +480,15 @@ EWN_DEV double d3_shaped_score(const FastTab<S> *Tb, const RState<S> &s)
 #ifndef D3_BS
 #define D3_BS 256
 #endif
+
+// bytes of STATIC LDS of k_step_d3<S, T, ., RNGK> (boards + terminal boards | table image | 16 bytes per game), 0 = the instance
+// takes its LDS dynamically (MT kind; blocks that would not fit the 64 KB static limit)
+template <int S, int T, int RNGK>
+constexpr int d3_lds_static()
+{
+    const int sz = ((2 * (D3_BS / T) * S * S + 15) & ~15) + FAST_TAB_BYTES(S) + (D3_BS / T) * 16;
+    return (RNGK == 1 && sz <= 60 * 1024) ? sz : 0;
+}
 #ifndef D3_REFILL_PRIO
 #define D3_REFILL_PRIO 3
 #define D3_STEP_PRIO 0
@@ -538,6 +561,23 @@ EWN_DEV void d3_encode(const FastTab<S> *Tb, const RState<S> &s, int sub, int8_t
     }
 }
 
+// the cube bytes only, into a board the caller has zeroed (ewn_rollout.hpp zeroes a wave's boards with 16-byte stores)
+template <int S, int T>
+EWN_DEV void d3_encode_cubes(const FastTab<S> *Tb, const RState<S> &s, int sub, int8_t *b)
+{
+    int cell[12];
+    #pragma unroll
+    for (int k = 0; k < 6; k++) {
+        cell[2 * k] = Tb->real_of_ring[pk_get(s.posN, k) & 63];
+        cell[2 * k + 1] = Tb->real_of_ring[pk_get(s.posP, k) & 63];
+    }
+    #pragma unroll
+    for (int k = 0; k < 6; k++) {
+        if (T == 1 || (2 * k) % T == sub) if (!(pk_get(s.posN, k) & PK_OFF)) b[cell[2 * k]] = (int8_t)(k + 1);
+        if (T == 1 || (2 * k + 1) % T == sub) if (!(pk_get(s.posP, k) & PK_OFF)) b[cell[2 * k + 1]] = (int8_t)(-(k + 1));
+    }
+}
+
 template <int S>
 EWN_DEV void d3_init_state(const FastTab<S> *Tb, RState<S> &s)
 {
@@ -556,7 +596,13 @@ template <int S, int T, int OPP, int RNGK>
 __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
 {
     constexpr int CELLS = S * S, GPB = D3_BS / T; // games per block
-    extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+    // Philox instances whose block fits keep their LDS in a STATIC array: a compile-time address folds into the offset field of
+    // every ds_read, the dynamic-LDS base costs one VALU add in front of every table read (ewn_rollout.hpp has the numbers).
+    // The MT kind sizes its LDS at launch (the refill role needs (W + 1) x 65 words).
+    extern __shared__ __attribute__((aligned(16))) int8_t lds_dyn[];
+    constexpr int LDS_ST = d3_lds_static<S, T, RNGK>();
+    __shared__ __attribute__((aligned(16))) int8_t lds_st[LDS_ST ? LDS_ST : 16];
+    int8_t *lds = LDS_ST ? lds_st : lds_dyn;
     // ---- MT kind with auto-reset: window refills ride along in this launch.  The step blocks of the PREVIOUS launch
     // parked (lane, slot, seed) requests in list[phase ^ 1]; the first refill_blocks blocks of THIS launch rebuild those
     // windows while the step blocks run (the 397+W-step recurrence is pure latency: hidden behind the step instead of
