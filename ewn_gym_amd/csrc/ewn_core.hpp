@@ -18,12 +18,13 @@ typedef uint32_t u32;
 // as a kernel argument, so every field is wave-uniform (SGPRs).
 struct Geom {
     int S, L, CN, cells;
-    u64 not_lastcol, not_lastrow, not_firstcol, not_firstrow, corner_br;
+    u64 not_lastcol, not_lastrow, not_firstcol, not_firstrow, corner_br; // boards up to 8x8 only (one 64-bit mask)
     u64 sq[8];          // sq[t] = cells with row >= t and col >= t  (distance to the bottom-right corner <= S-1-t)
-    int8_t init[64];    // initial board, envs/ewn.py:94-107
+    int8_t init[128];   // initial board, envs/ewn.py:94-107
     // the same position already decoded (GState layout), so reset() copies registers instead of scanning cells
-    u64 init_occP, init_occN, init_posP[2], init_posN[2];
+    u64 init_occP, init_occN, init_posP[3], init_posN[3];
     u32 init_alive;
+    u32 div_magic;      // (c * div_magic) >> 16 == c / S for every cell c (boards from 9x9: rows and columns by arithmetic)
 };
 
 // SIDE 0 = TOP_LEFT (positive numbers), SIDE 1 = BOTTOM_RIGHT (negative numbers).
@@ -34,11 +35,22 @@ struct GState {
     u32 aliveP, aliveN;
 };
 
+// NW == 3: boards from 9x9 to 11x11.  81..121 cells fit neither a 64-bit occupancy mask nor 6-bit positions, and nobody
+// benchmarks these sizes (the reference merely allows them: assert cube_layer < board_size - 1, envs/ewn.py:47), so the state is
+// mask-free -- 7-bit positions, nine per word, plus the alive masks -- and "what stands on cell q" is a scan over <= 30 cubes.
+// Every rule function below has an `if constexpr (NW == 3)` branch; the kernels are the same templates.
+template <>
+struct GState<3> {
+    u64 posP[3], posN[3];   // cube k (0-based) at bits [7*(k%9), +7) of word k/9
+    u32 aliveP, aliveN;
+};
+
 template <int NW>
 EWN_DEV int pos_get(const u64 (&w)[NW], int k)
 {
     if constexpr (NW == 1) return (int)((w[0] >> (6 * k)) & 63ull);
-    else return k < 10 ? (int)((w[0] >> (6 * k)) & 63ull) : (int)((w[1] >> (6 * (k - 10))) & 63ull);
+    else if constexpr (NW == 2) return k < 10 ? (int)((w[0] >> (6 * k)) & 63ull) : (int)((w[1] >> (6 * (k - 10))) & 63ull);
+    else { const int wi = k >= 9 ? 1 : 0; return (int)((w[wi] >> (7 * (k - 9 * wi))) & 127ull); } // <= 15 cubes: words 0 and 1
 }
 
 template <int NW>
@@ -46,9 +58,12 @@ EWN_DEV void pos_set(u64 (&w)[NW], int k, int c)
 {
     if constexpr (NW == 1) {
         w[0] = (w[0] & ~(63ull << (6 * k))) | ((u64)c << (6 * k));
-    } else {
+    } else if constexpr (NW == 2) {
         if (k < 10) w[0] = (w[0] & ~(63ull << (6 * k))) | ((u64)c << (6 * k));
         else w[1] = (w[1] & ~(63ull << (6 * (k - 10)))) | ((u64)c << (6 * (k - 10)));
+    } else {
+        if (k < 9) w[0] = (w[0] & ~(127ull << (7 * k))) | ((u64)c << (7 * k));
+        else w[1] = (w[1] & ~(127ull << (7 * (k - 9)))) | ((u64)c << (7 * (k - 9)));
     }
 }
 
@@ -63,12 +78,13 @@ template <int SIDE, int NW> EWN_DEV void set_pos_of(GState<NW> &s, int k, int c)
 template <int NW, class BytePtr>
 EWN_DEV void decode_board(const Geom &g, BytePtr b, GState<NW> &s)
 {
-    s.occP = s.occN = 0; s.aliveP = s.aliveN = 0;
+    s.aliveP = s.aliveN = 0;
+    if constexpr (NW != 3) s.occP = s.occN = 0;
     for (int w = 0; w < NW; w++) { s.posP[w] = 0; s.posN[w] = 0; }
     for (int c = 0; c < g.cells; c++) {
         int v = (int)(int8_t)b[c];
-        if (v > 0 && v <= g.CN) { s.occP |= 1ull << c; s.aliveP |= 1u << (v - 1); pos_set<NW>(s.posP, v - 1, c); }
-        else if (v < 0 && -v <= g.CN) { s.occN |= 1ull << c; s.aliveN |= 1u << (-v - 1); pos_set<NW>(s.posN, -v - 1, c); }
+        if (v > 0 && v <= g.CN) { if constexpr (NW != 3) s.occP |= 1ull << c; s.aliveP |= 1u << (v - 1); pos_set<NW>(s.posP, v - 1, c); }
+        else if (v < 0 && -v <= g.CN) { if constexpr (NW != 3) s.occN |= 1ull << c; s.aliveN |= 1u << (-v - 1); pos_set<NW>(s.posN, -v - 1, c); }
     }
 }
 
@@ -85,7 +101,8 @@ EWN_DEV void encode_board(const Geom &g, const GState<NW> &s, BytePtr b)
 template <int NW>
 EWN_DEV void init_state(const Geom &g, GState<NW> &s)
 {
-    s.occP = g.init_occP; s.occN = g.init_occN; s.aliveP = s.aliveN = g.init_alive;
+    if constexpr (NW != 3) { s.occP = g.init_occP; s.occN = g.init_occN; }
+    s.aliveP = s.aliveN = g.init_alive;
     for (int w = 0; w < NW; w++) { s.posP[w] = g.init_posP[w]; s.posN[w] = g.init_posN[w]; }
 }
 
@@ -94,13 +111,17 @@ template <int NW>
 EWN_DEV GState<NW> canonicalize(const Geom &g, const GState<NW> &s)
 {
     GState<NW> c;
-    const int sh = 64 - g.cells;
-    c.occP = __brevll(s.occN) >> sh;
-    c.occN = __brevll(s.occP) >> sh;
     c.aliveP = s.aliveN; c.aliveN = s.aliveP;
-    // fieldwise (cells-1) - pos: every 6-bit field holds a value <= cells-1, so no borrow crosses fields
+    // fieldwise (cells-1) - pos: every field holds a value <= cells-1, so no borrow crosses fields
     u64 rep = 0;
-    for (int k = 0; k < 10; k++) rep |= (u64)(g.cells - 1) << (6 * k);
+    if constexpr (NW == 3) {
+        for (int k = 0; k < 9; k++) rep |= (u64)(g.cells - 1) << (7 * k);
+    } else {
+        const int sh = 64 - g.cells;
+        c.occP = __brevll(s.occN) >> sh;
+        c.occN = __brevll(s.occP) >> sh;
+        for (int k = 0; k < 10; k++) rep |= (u64)(g.cells - 1) << (6 * k);
+    }
     for (int w = 0; w < NW; w++) { c.posP[w] = rep - s.posN[w]; c.posN[w] = rep - s.posP[w]; }
     return c;
 }
@@ -109,7 +130,25 @@ EWN_DEV GState<NW> canonicalize(const Geom &g, const GState<NW> &s)
 template <int NW>
 EWN_DEV bool is_win(const Geom &g, const GState<NW> &s)
 {
-    return (s.occN & 1ull) || (s.occP & g.corner_br) || s.occP == 0 || s.occN == 0;
+    if constexpr (NW == 3) {
+        bool home = false;
+        for (int k = 0; k < g.CN; k++) {
+            home |= ((s.aliveP >> k) & 1u) && pos_get<3>(s.posP, k) == g.cells - 1;
+            home |= ((s.aliveN >> k) & 1u) && pos_get<3>(s.posN, k) == 0;
+        }
+        return home || s.aliveP == 0 || s.aliveN == 0;
+    } else return (s.occN & 1ull) || (s.occP & g.corner_br) || s.occP == 0 || s.occN == 0;
+}
+
+// mcts.py:39-41 / minimax_ewn.py:233-235: TOP_LEFT has won a finished playout (its cube on the far corner, or no opponent left)
+template <int NW>
+EWN_DEV bool top_left_won(const Geom &g, const GState<NW> &s)
+{
+    if constexpr (NW == 3) {
+        bool home = false;
+        for (int k = 0; k < g.CN; k++) home |= ((s.aliveP >> k) & 1u) && pos_get<3>(s.posP, k) == g.cells - 1;
+        return home || s.aliveN == 0;
+    } else return (s.occP & g.corner_br) || s.occN == 0;
 }
 
 // Dice -> candidate cubes (find_near_cube, envs/ewn.py:144-176; both players index by
@@ -142,6 +181,11 @@ EWN_DEV int cube_to_move(const CubeSel &c, bool larger)
 template <int SIDE>
 EWN_DEV bool dir_ok(const Geom &g, int c, int dir)
 {
+    if (g.S > 8) { // no 64-bit mask of the board: row and column by arithmetic
+        const int row = (int)(((u32)c * g.div_magic) >> 16), col = c - row * g.S;
+        const bool col_ok = SIDE == 0 ? col < g.S - 1 : col > 0, row_ok = SIDE == 0 ? row < g.S - 1 : row > 0;
+        return dir == 0 ? col_ok : (dir == 1 ? row_ok : (col_ok && row_ok));
+    }
     const u64 b = 1ull << c;
     const u64 colm = SIDE == 0 ? g.not_lastcol : g.not_firstcol;
     const u64 rowm = SIDE == 0 ? g.not_lastrow : g.not_firstrow;
@@ -163,7 +207,7 @@ EWN_DEV void kill_at(const Geom &g, GState<NW> &s, int q)
     for (int k = 0; k < g.CN; k++)
         if (((a >> k) & 1u) && pos_of<SIDE>(s, k) == q) a &= ~(1u << k);
     alive_of<SIDE>(s) = a;
-    occ_of<SIDE>(s) &= ~(1ull << q);
+    if constexpr (NW != 3) occ_of<SIDE>(s) &= ~(1ull << q);
 }
 
 // execute_move / make_simulated_action for a move already known to stay on the board
@@ -173,10 +217,15 @@ EWN_DEV void apply_move(const Geom &g, GState<NW> &s, int k, int dir)
 {
     const int p = pos_of<SIDE>(s, k);
     const int q = dest_cell<SIDE>(g, p, dir);
-    const u64 bq = 1ull << q;
-    if (occ_of<1 - SIDE>(s) & bq) kill_at<1 - SIDE>(g, s, q);
-    else if (occ_of<SIDE>(s) & bq) kill_at<SIDE>(g, s, q);
-    occ_of<SIDE>(s) = (occ_of<SIDE>(s) & ~(1ull << p)) | bq;
+    if constexpr (NW == 3) {
+        kill_at<1 - SIDE>(g, s, q);   // at most one cube stands on q, of either side; the scans simply find nothing otherwise
+        kill_at<SIDE>(g, s, q);
+    } else {
+        const u64 bq = 1ull << q;
+        if (occ_of<1 - SIDE>(s) & bq) kill_at<1 - SIDE>(g, s, q);
+        else if (occ_of<SIDE>(s) & bq) kill_at<SIDE>(g, s, q);
+        occ_of<SIDE>(s) = (occ_of<SIDE>(s) & ~(1ull << p)) | bq;
+    }
     set_pos_of<SIDE>(s, k, q);
 }
 
@@ -219,6 +268,33 @@ EWN_DEV int min_dist_br(const Geom &g, u64 m)
 template <int NW>
 EWN_DEV double evaluate(const Geom &g, const GState<NW> &s, int heur)
 {
+    if constexpr (NW == 3) {
+        // boards from 9x9: the same arithmetic from the cube positions (distance of a cube = max(S-1-row, S-1-col))
+        if (top_left_won<3>(g, s)) return 10.0;                     // :42-44
+        bool n_home = false;
+        for (int k = 0; k < g.CN; k++) n_home |= ((s.aliveN >> k) & 1u) && pos_get<3>(s.posN, k) == 0;
+        if (n_home || s.aliveP == 0) return -10.0;                  // :45-47
+        const int np = __popc(s.aliveP), nn = __popc(s.aliveN);
+        if (heur == 3) return (double)(-(np + nn));
+        int p1 = 1 << 20, p2 = 1 << 20, n1 = 1 << 20, n2 = 1 << 20; // the two smallest distances of either side
+        for (int k = 0; k < g.CN; k++) {
+            #pragma unroll
+            for (int side = 0; side < 2; side++) {
+                if (!(((side ? s.aliveN : s.aliveP) >> k) & 1u)) continue;
+                const int c = pos_get<3>(side ? s.posN : s.posP, k);
+                const int row = (int)(((u32)c * g.div_magic) >> 16), col = c - row * g.S;
+                const int d = max(g.S - 1 - row, g.S - 1 - col);
+                int &a = side ? n1 : p1, &b = side ? n2 : p2;
+                if (d < a) { b = a; a = d; } else if (d < b) b = d;
+            }
+        }
+        if (heur == 2) return (double)((n1 + (nn >= 2 ? n2 : 0)) - (p1 + (np >= 2 ? p2 : 0)));   // two_min_dist :157-174
+        if (heur == 1) return (double)((g.S - p1) - (g.S - n1));    // min_dist :126-127
+        const double a = (double)(g.S - p1) * (1.0 / (double)np);   // hybrid :79-80
+        const double b = (double)(g.S - n1) * (1.0 / (double)nn);   // :81-82
+        return (0.0 + a) - b;
+    } else {
+
     if ((s.occP & g.corner_br) || s.occN == 0) return 10.0;     // :42-44
     if ((s.occN & 1ull) || s.occP == 0) return -10.0;           // :45-47
     const int np = __popcll(s.occP), nn = __popcll(s.occN);
@@ -239,6 +315,7 @@ EWN_DEV double evaluate(const Geom &g, const GState<NW> &s, int heur)
     const double a = (double)(g.S - mdp) * (1.0 / (double)np);  // hybrid :79-80
     const double b = (double)(g.S - mdn) * (1.0 / (double)nn);  // :81-82
     return (0.0 + a) - b;
+    }
 }
 
 // ---------------------------------------------------------------- expectiminimax

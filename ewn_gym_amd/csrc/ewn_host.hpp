@@ -33,19 +33,22 @@ static inline bool make_geom(int S, int L, Geom &g)
     const int CN = L * (L + 1) / 2;
     if (CN > EWN_MAX_CUBES) return false;
     g.S = S; g.L = L; g.CN = CN; g.cells = S * S;
+    g.div_magic = 65536u / (u32)S + 1u;
     g.not_lastcol = g.not_lastrow = g.not_firstcol = g.not_firstrow = 0;
     for (int t = 0; t < 8; t++) g.sq[t] = 0;
-    for (int i = 0; i < S; i++)
-        for (int j = 0; j < S; j++) {
-            const u64 b = 1ull << (i * S + j);
-            if (j < S - 1) g.not_lastcol |= b;
-            if (i < S - 1) g.not_lastrow |= b;
-            if (j > 0) g.not_firstcol |= b;
-            if (i > 0) g.not_firstrow |= b;
-            for (int t = 0; t < S; t++) if (i >= t && j >= t) g.sq[t] |= b;
-        }
-    g.corner_br = 1ull << (S * S - 1);
-    for (int c = 0; c < 64; c++) g.init[c] = 0;
+    const bool wide = S > 8; // 9x9 .. 11x11: no 64-bit masks, 7-bit positions nine per word (ewn_core.hpp GState<3>)
+    if (!wide)
+        for (int i = 0; i < S; i++)
+            for (int j = 0; j < S; j++) {
+                const u64 b = 1ull << (i * S + j);
+                if (j < S - 1) g.not_lastcol |= b;
+                if (i < S - 1) g.not_lastrow |= b;
+                if (j > 0) g.not_firstcol |= b;
+                if (i > 0) g.not_firstrow |= b;
+                for (int t = 0; t < S; t++) if (i >= t && j >= t) g.sq[t] |= b;
+            }
+    g.corner_br = wide ? 0 : 1ull << (S * S - 1);
+    for (int c = 0; c < 128; c++) g.init[c] = 0;
     int cnt = 1;
     for (int i = 1; i <= L; i++)
         for (int j = 0; j < i; j++) {
@@ -54,11 +57,12 @@ static inline bool make_geom(int S, int L, Geom &g)
             cnt++;
         }
     g.init_occP = g.init_occN = 0; g.init_alive = 0;
-    for (int w = 0; w < 2; w++) g.init_posP[w] = g.init_posN[w] = 0;
+    for (int w = 0; w < 3; w++) g.init_posP[w] = g.init_posN[w] = 0;
+    const int per = wide ? 9 : 10, bits = wide ? 7 : 6;
     for (int c = 0; c < S * S; c++) {
         const int v = g.init[c];
-        if (v > 0) { g.init_occP |= 1ull << c; g.init_alive |= 1u << (v - 1); g.init_posP[(v - 1) / 10] |= (u64)c << (6 * ((v - 1) % 10)); }
-        if (v < 0) { g.init_occN |= 1ull << c; g.init_posN[(-v - 1) / 10] |= (u64)c << (6 * ((-v - 1) % 10)); }
+        if (v > 0) { if (!wide) g.init_occP |= 1ull << c; g.init_alive |= 1u << (v - 1); g.init_posP[(v - 1) / per] |= (u64)c << (bits * ((v - 1) % per)); }
+        if (v < 0) { if (!wide) g.init_occN |= 1ull << c; g.init_posN[(-v - 1) / per] |= (u64)c << (bits * ((-v - 1) % per)); }
     }
     return true;
 }

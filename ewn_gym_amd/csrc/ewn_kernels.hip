@@ -363,7 +363,7 @@ __global__ __launch_bounds__(BS) void k_playout_wins(Geom g, int M, int n_sims, 
         if (cur == 0) rollout_ply<0, NW>(g, s, ps); else rollout_ply<1, NW>(g, s, ps);
         cur ^= 1;
     }
-    if ((s.occP & g.corner_br) || s.occN == 0) atomicAdd(&wins[m], 1);
+    if (top_left_won<NW>(g, s)) atomicAdd(&wins[m], 1);
 }
 
 // the same for cube_layer <= 3 (ewn_playout.hpp): an aligned group of 2^gl lanes per position, lane t plays playouts
@@ -541,7 +541,7 @@ struct SimLeaf {
                 cur ^= 1;                                               // self.switch_player()
                 if (cur == 0) rollout_ply<0, NW>(g, s, ps); else rollout_ply<1, NW>(g, s, ps);
             }
-            wins += ((s.occP & g.corner_br) || s.occN == 0) ? 1 : 0;    // :233-235
+            wins += top_left_won<NW>(g, s) ? 1 : 0;    // :233-235
         }
         return (double)wins / (double)nsims;
     }
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(BS) void k_mcts_rollout(Geom g, int M, int total, c
         if (cur == 0) rollout_ply<0, NW>(g, s, ps); else rollout_ply<1, NW>(g, s, ps);
         cur ^= 1;
     }
-    if ((s.occP & g.corner_br) || s.occN == 0) atomicAdd(&wins[(size_t)m * 6 + i], 1); // mcts.py:39-41
+    if (top_left_won<NW>(g, s)) atomicAdd(&wins[(size_t)m * 6 + i], 1); // mcts.py:39-41
 }
 
 // the same for cube_layer <= 3 (ewn_playout.hpp).  A block owns opb <= 10 observations = up to 60 root-move slots, lists
@@ -663,7 +663,9 @@ __global__ __launch_bounds__(BS) void k_mcts_pick(Geom g, int M, const int8_t *b
 // ---------------------------------------------------------------- host side: C ABI
 
 #define GRID(n) dim3((unsigned)(((long long)(n) + BS - 1) / BS))
-#define BY_NW(g, expr1, expr2) do { if ((g).CN <= 10) { expr1; } else { expr2; } } while (0)
+// NWV = words of packed cube positions per side: 1 (<= 10 cubes) or 2 on boards up to 8x8 (64-bit occupancy masks, 6-bit positions),
+// 3 = the mask-free state of boards from 9x9 to 11x11 (7-bit positions, ewn_core.hpp GState<3>)
+#define BY_NW(g, X) do { if ((g).S > 8) { constexpr int NWV = 3; X; } else if ((g).CN <= 10) { constexpr int NWV = 1; X; } else { constexpr int NWV = 2; X; } } while (0)
 
 template <int NW>
 static void launch_minimax(const Geom &g, int M, const int8_t *boards, const int8_t *dice, int depth, int heur, int8_t *actions,
@@ -785,8 +787,7 @@ int ewn_init_aux(const ewn_config *cfg, const ewn_state *st, void *stream)
     if (!st || !st->done || !st->rng) return EWN_ENULL;
     if (cfg->shaped && (!st->prev_score || !st->tolerance)) return EWN_ENULL;
     hipStream_t s = (hipStream_t)stream;
-    BY_NW(g, (k_init_aux<1><<<GRID(k.N), BS, 0, s>>>(g, k, kstate(st), cfg->illegal_move_tolerance)),
-          (k_init_aux<2><<<GRID(k.N), BS, 0, s>>>(g, k, kstate(st), cfg->illegal_move_tolerance)));
+    BY_NW(g, (k_init_aux<NWV><<<GRID(k.N), BS, 0, s>>>(g, k, kstate(st), cfg->illegal_move_tolerance)));
     return launch_status();
 }
 
@@ -798,8 +799,7 @@ int ewn_reset(const ewn_config *cfg, const ewn_state *st, const uint32_t *seeds,
     if (!st || !st->board || !st->dice || !st->done || !st->rng) return EWN_ENULL;
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = (size_t)BS * g.cells;
-    BY_NW(g, (k_reset<1><<<GRID(k.N), BS, lds, s>>>(g, k, kstate(st), seeds, lane_mask)),
-          (k_reset<2><<<GRID(k.N), BS, lds, s>>>(g, k, kstate(st), seeds, lane_mask)));
+    BY_NW(g, (k_reset<NWV><<<GRID(k.N), BS, lds, s>>>(g, k, kstate(st), seeds, lane_mask)));
     return launch_status();
 }
 
@@ -809,17 +809,14 @@ int ewn_predict_mcts(int board_size, int cube_layer, int M, const int8_t *boards
 static int mcts_launch(const Geom &g, int M, const int8_t *boards, const int8_t *dice, const uint8_t *active, int total, u64 key,
                        const u32 *obs_id, int8_t *actions, int32_t *wins, hipStream_t s)
 {
-    const bool lean = g.CN <= 6;
+    const bool lean = g.CN <= 6 && g.S <= 8; // the byte-per-cube playout numbers cells row * 8 + col
     const int gl = playout_group_log2(total), opb = mcts_obs_per_block(gl);
     const long long threads = lean ? (((long long)M + opb - 1) / opb) * BS : (long long)M * 6 * total;
     if (threads > 0x7fffffffll * BS) return EWN_EINVAL;
-    BY_NW(g, (k_mcts_init<1><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, active, wins)),
-          (k_mcts_init<2><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, active, wins)));
+    BY_NW(g, (k_mcts_init<NWV><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, active, wins)));
     if (lean) k_mcts_rollout_lean<<<GRID(threads), BS, 0, s>>>(g, M, total, gl, opb, boards, dice, obs_id, key, wins);
-    else BY_NW(g, (k_mcts_rollout<1><<<GRID(threads), BS, 0, s>>>(g, M, total, boards, dice, obs_id, key, wins)),
-               (k_mcts_rollout<2><<<GRID(threads), BS, 0, s>>>(g, M, total, boards, dice, obs_id, key, wins)));
-    BY_NW(g, (k_mcts_pick<1><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, wins, actions)),
-          (k_mcts_pick<2><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, wins, actions)));
+    else BY_NW(g, (k_mcts_rollout<NWV><<<GRID(threads), BS, 0, s>>>(g, M, total, boards, dice, obs_id, key, wins)));
+    BY_NW(g, (k_mcts_pick<NWV><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, wins, actions)));
     return launch_status();
 }
 
@@ -867,21 +864,17 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
             default: k_step<1, 0, 8><<<GRID(k.N), BS, base + FAST_TAB_BYTES(8), s>>>(g, k, ks, actions, ko, sc); break;
             }
         } else {
-            BY_NW(g, (k_step<1, 0, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)),
-                  (k_step<2, 0, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)));
+            BY_NW(g, (k_step<NWV, 0, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)));
         }
     } else {
-        BY_NW(g, (k_step<1, 1, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)),
-              (k_step<2, 1, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)));
+        BY_NW(g, (k_step<NWV, 1, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)));
         rc = launch_status();
         if (rc) return rc;
         if (sim_opp) {
-            BY_NW(g, rc = launch_minimax_sim<1>(g, k.N, sc.cboard, sc.cdice, sc.phase, sc.obs_id, k.key, k.depth, sc.act, nullptr, s),
-                  rc = launch_minimax_sim<2>(g, k.N, sc.cboard, sc.cdice, sc.phase, sc.obs_id, k.key, k.depth, sc.act, nullptr, s));
+            BY_NW(g, rc = launch_minimax_sim<NWV>(g, k.N, sc.cboard, sc.cdice, sc.phase, sc.obs_id, k.key, k.depth, sc.act, nullptr, s));
         } else rc = mcts_launch(g, k.N, sc.cboard, sc.cdice, sc.phase, k.nsim_total, k.key, sc.obs_id, sc.act, sc.wins, s);
         if (rc) return rc;
-        BY_NW(g, (k_step<1, 2, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)),
-              (k_step<2, 2, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)));
+        BY_NW(g, (k_step<NWV, 2, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)));
     }
     rc = launch_status();
     if (rc) return rc;
@@ -984,8 +977,7 @@ int ewn_legal_actions(int board_size, int cube_layer, int M, const int8_t *board
     if (M == 0) return EWN_OK;
     if (!dice) return EWN_ENULL;
     hipStream_t s = (hipStream_t)stream;
-    BY_NW(g, (k_legal<1><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, player, acts, n_acts, cube_small, cube_large, win)),
-          (k_legal<2><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, player, acts, n_acts, cube_small, cube_large, win)));
+    BY_NW(g, (k_legal<NWV><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, player, acts, n_acts, cube_small, cube_large, win)));
     return launch_status();
 }
 
@@ -999,8 +991,7 @@ int ewn_apply_action(int board_size, int cube_layer, int M, const int8_t *boards
     if (M == 0) return EWN_OK;
     if (!dice || !actions || !new_boards) return EWN_ENULL;
     hipStream_t s = (hipStream_t)stream;
-    BY_NW(g, (k_apply_action<1><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, player, actions, new_boards, valid)),
-          (k_apply_action<2><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, player, actions, new_boards, valid)));
+    BY_NW(g, (k_apply_action<NWV><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, player, actions, new_boards, valid)));
     return launch_status();
 }
 
@@ -1016,7 +1007,7 @@ int ewn_playout_wins(int board_size, int cube_layer, int M, const int8_t *boards
     if (!wins) return EWN_ENULL;
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(wins, 0, (size_t)M * sizeof(int32_t), s) != hipSuccess) return EWN_ELAUNCH;
-    if (g.CN <= 6) {
+    if (g.CN <= 6 && g.S <= 8) {
         const int gl = playout_group_log2(n_sims);
         const long long threads = (long long)M << gl;
         if (threads > 0x7fffffffll * BS) return EWN_EINVAL;
@@ -1025,8 +1016,7 @@ int ewn_playout_wins(int board_size, int cube_layer, int M, const int8_t *boards
     }
     const long long threads = (long long)M * n_sims;
     if (threads > 0x7fffffffll * BS) return EWN_EINVAL;
-    BY_NW(g, (k_playout_wins<1><<<GRID(threads), BS, 0, s>>>(g, M, n_sims, boards, first_player, key, wins)),
-          (k_playout_wins<2><<<GRID(threads), BS, 0, s>>>(g, M, n_sims, boards, first_player, key, wins)));
+    BY_NW(g, (k_playout_wins<NWV><<<GRID(threads), BS, 0, s>>>(g, M, n_sims, boards, first_player, key, wins)));
     return launch_status();
 }
 
@@ -1039,8 +1029,7 @@ int ewn_evaluate(int board_size, int cube_layer, int M, const int8_t *boards, in
     if (M == 0) return EWN_OK;
     if (!out) return EWN_ENULL;
     hipStream_t s = (hipStream_t)stream;
-    BY_NW(g, (k_evaluate<1><<<GRID(M), BS, 0, s>>>(g, M, boards, heuristic, out)),
-          (k_evaluate<2><<<GRID(M), BS, 0, s>>>(g, M, boards, heuristic, out)));
+    BY_NW(g, (k_evaluate<NWV><<<GRID(M), BS, 0, s>>>(g, M, boards, heuristic, out)));
     return launch_status();
 }
 
@@ -1059,8 +1048,7 @@ int ewn_predict_minimax(int board_size, int cube_layer, int M, const int8_t *boa
     if (heuristic == EWN_H_SIM_WINRATE) {
         // the playout randomness: one generator per observation from (index, sim_key); ewn_predict_minimax has no key argument,
         // ewn_predict_minimax_sim (below) takes one
-        BY_NW(g, rc = launch_minimax_sim<1>(g, M, boards, dice, nullptr, nullptr, 0, max_depth, actions, values, s),
-              rc = launch_minimax_sim<2>(g, M, boards, dice, nullptr, nullptr, 0, max_depth, actions, values, s));
+        BY_NW(g, rc = launch_minimax_sim<NWV>(g, M, boards, dice, nullptr, nullptr, 0, max_depth, actions, values, s));
         return rc;
     }
     if (tables && fast_tables_bytes(g.S, g.L) > 0 && max_depth <= 6 && fast_heur_image(heuristic) >= 0) {
@@ -1073,8 +1061,7 @@ int ewn_predict_minimax(int board_size, int cube_layer, int M, const int8_t *boa
         }
         return launch_status();
     }
-    BY_NW(g, launch_minimax<1>(g, M, boards, dice, max_depth, heuristic, actions, values, s),
-          launch_minimax<2>(g, M, boards, dice, max_depth, heuristic, actions, values, s));
+    BY_NW(g, launch_minimax<NWV>(g, M, boards, dice, max_depth, heuristic, actions, values, s));
     return launch_status();
 }
 
@@ -1089,8 +1076,7 @@ int ewn_predict_minimax_sim(int board_size, int cube_layer, int M, const int8_t 
     if (M == 0) return EWN_OK;
     if (!dice || !actions) return EWN_ENULL;
     hipStream_t s = (hipStream_t)stream;
-    BY_NW(g, rc = launch_minimax_sim<1>(g, M, boards, dice, nullptr, obs_id, key, max_depth, actions, values, s),
-          rc = launch_minimax_sim<2>(g, M, boards, dice, nullptr, obs_id, key, max_depth, actions, values, s));
+    BY_NW(g, rc = launch_minimax_sim<NWV>(g, M, boards, dice, nullptr, obs_id, key, max_depth, actions, values, s));
     return rc;
 }
 
@@ -1103,8 +1089,7 @@ int ewn_predict_random(int board_size, int cube_layer, int M, const int8_t *boar
     if (M == 0) return EWN_OK;
     if (!dice || !actions) return EWN_ENULL;
     hipStream_t s = (hipStream_t)stream;
-    BY_NW(g, (k_predict_random<1><<<GRID(M), BS, (size_t)BS * g.cells, s>>>(g, M, boards, dice, key, step, step_dev, lane_offset, actions)),
-          (k_predict_random<2><<<GRID(M), BS, (size_t)BS * g.cells, s>>>(g, M, boards, dice, key, step, step_dev, lane_offset, actions)));
+    BY_NW(g, (k_predict_random<NWV><<<GRID(M), BS, (size_t)BS * g.cells, s>>>(g, M, boards, dice, key, step, step_dev, lane_offset, actions)));
     return launch_status();
 }
 

@@ -41,7 +41,7 @@ extern "C" {
 #define EWN_EINVAL (-1)      /* bad argument / unsupported configuration (the reference asserts, envs/ewn.py:47) */
 #define EWN_ENULL (-2)       /* required pointer is NULL */
 #define EWN_ELAUNCH (-3)     /* kernel launch failed (hipGetLastError != hipSuccess) */
-#define EWN_EUNSUPPORTED (-4)/* valid in the reference, not built here (e.g. board_size > 8, 'sim_winrate' deeper than 4) */
+#define EWN_EUNSUPPORTED (-4)/* valid in the reference, not built here (e.g. board_size > 11, 'sim_winrate' deeper than 4) */
 
 /* opponent_kind: constants/policy.py:4-10 (uct / alpha_zero are out of scope) */
 #define EWN_OPP_RANDOM 0
@@ -70,7 +70,8 @@ extern "C" {
 #define EWN_INFO_LOST 4           /* "You lost!" */
 #define EWN_INFO_TOLERANCE 5      /* "Invalid move for player! Tolerance left {n}." */
 
-#define EWN_MAX_BOARD 8   /* S*S bits must fit one 64-bit occupancy mask */
+#define EWN_MAX_BOARD 11  /* up to 8x8: 64-bit occupancy masks and the table-driven kernels; 9x9 .. 11x11: the generic kernels on a
+                             mask-free state (7-bit positions) */
 #define EWN_MAX_CUBES 15  /* cube_layer <= 5 */
 #define EWN_MAX_DEPTH 6
 #define EWN_MT_WINDOW_MAX 227 /* MT19937 outputs computable from the seeded state alone */
@@ -80,7 +81,7 @@ extern "C" {
  * MiniMaxHeuristicEnv (envs/training_ewn.py:19-29) and the opponent policy ctor
  * kwargs (classical_policies/minimax.py:10-11, mcts.py:11-13). */
 typedef struct ewn_config {
-    int32_t board_size;             /* S, 3..8 */
+    int32_t board_size;             /* S, 3..EWN_MAX_BOARD */
     int32_t cube_layer;             /* L, cube_num = L(L+1)/2, L < S-1 */
     int32_t n_lanes;                /* N parallel games handled by this call */
     int32_t opponent_kind;          /* EWN_OPP_* */

@@ -65,7 +65,8 @@ def test_config_validation_on_host():
     assert lib.ewn_rng_words(C.byref(cfg(mt_window=227))) == 4 + 3 * 227 + 1
     assert lib.ewn_rng_words(C.byref(cfg(mt_window=228))) == -1
     assert lib.ewn_rng_words(C.byref(cfg(cube_layer=4))) == -1            # assert cube_layer < board_size - 1 (envs/ewn.py:47)
-    assert lib.ewn_rng_words(C.byref(cfg(board_size=9, cube_layer=3))) == -4  # valid upstream, > 64-bit mask here
+    assert lib.ewn_rng_words(C.byref(cfg(board_size=9, cube_layer=3))) == 4 + 3 * 128 + 1   # 9x9 .. 11x11: mask-free generic kernels
+    assert lib.ewn_rng_words(C.byref(cfg(board_size=12, cube_layer=3))) == -4  # valid upstream, not built here (7-bit positions)
     assert lib.ewn_rng_words(C.byref(cfg(n_lanes=0))) == -1
     assert lib.ewn_rng_words(C.byref(cfg(opponent_kind=1, max_depth=7))) == -4
     assert lib.ewn_rng_words(C.byref(cfg(opponent_kind=1, cube_layer=2))) == -4  # dice loop 1..6 needs 6 cubes

@@ -31,7 +31,7 @@ def _replay(env, rec):
 def test_env_random_opponent_trajectories(golden):
     import envs
     from constants import ClassicalPolicy
-    g = [r for r in golden("g3_traj_random.json") if r["S"] <= 8]
+    g = golden("g3_traj_random.json")
     for (S, L) in sorted({(r["S"], r["L"]) for r in g}):
         env = envs.EinsteinWuerfeltNichtEnv(board_size=S, cube_layer=L, opponent_policy=ClassicalPolicy.random)
         assert type(env.opponent_policy).__name__ == "RandomAgent"

@@ -47,10 +47,6 @@ def cpu(t):
 def test_g1_reset(ea, golden):
     g = golden("g1_initial.json")
     for (S, L) in sorted({(r["S"], r["L"]) for r in g}):
-        if S > 8:
-            with pytest.raises(ea.EwnError):
-                ea.VecEWN(4, board_size=S, cube_layer=L)
-            continue
         recs = [r for r in g if (r["S"], r["L"]) == (S, L)]
         env = ea.VecEWN(len(recs), board_size=S, cube_layer=L, rng="mt19937")
         b, d = env.reset(seeds=[r["seed"] for r in recs])
@@ -59,7 +55,7 @@ def test_g1_reset(ea, golden):
 
 
 def test_g2_legal_actions(ea, golden):
-    g = [r for r in golden("g2_legal.json") if r["S"] <= 8]
+    g = golden("g2_legal.json")
     for (S, L, pl) in sorted({(r["S"], r["L"], r["player"]) for r in g}):
         recs = [r for r in g if (r["S"], r["L"], r["player"]) == (S, L, pl)]
         acts, n, cs, cl, win = [cpu(t) for t in ea.legal_actions(boards_of(recs, S), [r["dice"] for r in recs], player=pl, cube_layer=L)]
@@ -788,3 +784,41 @@ def test_philox_streams_do_not_repeat_when_the_seed_wraps(ea):
     key = np.array([77, 0], np.uint32)
     differ = sum(int(not np.array_equal(philox([0, s, 0, 0x454E5631], key), philox([0, s, 1, 0x454E5631], key))) for s in cur_seed[:16])
     assert differ == 16
+
+
+@pytest.mark.parametrize("S,L", [(9, 3), (9, 5), (10, 4), (11, 5)])
+def test_boards_larger_than_8x8(ea, S, L):
+    """9x9 .. 11x11 (the reference only asserts cube_layer < board_size - 1): 81..121 cells fit no 64-bit mask, the generic kernels
+    run on a mask-free state (7-bit positions).  Lock-step against the oracle with every opponent kind, the stateless queries,
+    the heuristics; 12x12 is refused."""
+    _lockstep(ea, 400, 60, board_size=S, cube_layer=L, rng="mt19937")
+    _lockstep(ea, 200, 30, board_size=S, cube_layer=L, rng="philox", philox_key=S, shaped=True, illegal_move_tolerance=3)
+    if L >= 3:
+        _lockstep(ea, 160, 16, board_size=S, cube_layer=L, opponent_policy="minimax", max_depth=2, rng="philox", philox_key=S + 1)
+        _lockstep(ea, 64, 8, board_size=S, cube_layer=L, opponent_policy="minimax", max_depth=3, heuristic="two_min_dist", rng="mt19937")
+        _lockstep(ea, 48, 8, board_size=S, cube_layer=L, opponent_policy="mcts", num_simulations=3, num_env_copies=2, rng="philox", philox_key=S + 2)
+        b, d = _random_positions(S, L, 300, 50 + S, max_steps=40)
+        d = np.minimum(d, 6).astype(np.int8)
+        for depth, heur in ((1, "hybrid"), (2, "min_dist"), (3, "hybrid"), (3, "attk"), (2, "two_min_dist")):
+            acts, vals = ea.predict_minimax(b, d, depth, heur, cube_layer=L)
+            oa, ov, _ = po.predict_minimax(b, d, depth, heur, cube_layer=L)
+            assert np.array_equal(cpu(acts), oa) and np.array_equal(bits(cpu(vals)), bits(ov)), (depth, heur)
+        for h in ("hybrid", "min_dist", "two_min_dist", "attk"):
+            assert np.array_equal(bits(cpu(ea.evaluate(b, h, cube_layer=L))), bits(po.evaluate(b, h, cube_layer=L))), h
+        acts, wins = ea.predict_mcts(b[:40], d[:40], num_simulations=9, num_env_copies=1, key=S, cube_layer=L)
+        oa, ow = po.predict_mcts(b[:40], d[:40], num_simulations=9, num_env_copies=1, key=S, cube_layer=L)
+        assert np.array_equal(cpu(wins), ow) and np.array_equal(cpu(acts), oa)
+        w = ea.playout_wins(b[:40], first_player=2, n_sims=17, key=3, cube_layer=L)
+        assert np.array_equal(cpu(w), po.playout_wins(b[:40], 2, 17, key=3, cube_layer=L))
+    for player in (1, 2):
+        pb, pd = _random_positions(S, L, 200, 7 + S + player, max_steps=30)
+        pd = np.minimum(pd, L * (L + 1) // 2).astype(np.int8)
+        got = [cpu(t) for t in ea.legal_actions(pb, pd, player=player, cube_layer=L)]
+        exp = po.legal_actions(pb, pd, player=player, cube_layer=L)
+        for k, (a, o) in enumerate(zip(got, exp)):
+            if k == 0:
+                a = np.where(a < 0, 0, a)   # the engine pads the list with -1, the oracle with 0
+                o = np.where(np.arange(6)[None, :, None] < exp[1][:, None, None], o, 0)
+            assert np.array_equal(a, o), (player, k)
+    with pytest.raises(ea.EwnError):
+        ea.VecEWN(4, board_size=12, cube_layer=3)
