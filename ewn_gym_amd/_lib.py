@@ -23,7 +23,7 @@ INFO_MESSAGES = {
 EXPORTS = ["ewn_abi_version", "ewn_strerror", "ewn_rng_words", "ewn_step_scratch_bytes", "ewn_tables_bytes",
            "ewn_build_tables", "ewn_init_aux", "ewn_reset",
            "ewn_step", "ewn_legal_actions", "ewn_apply_action", "ewn_playout_wins", "ewn_evaluate", "ewn_predict_minimax", "ewn_predict_random",
-           "ewn_predict_mcts", "ewn_step_k", "ewn_step_k_supported", "ewn_predict_minimax_sim"]
+           "ewn_predict_mcts", "ewn_step_k", "ewn_step_k_supported", "ewn_predict_minimax_sim", "ewn_lanes_per_game"]
 AGENT = {"random": 0, "minimax": 1}
 
 
@@ -53,7 +53,8 @@ class EwnStepOut(C.Structure):  # struct ewn_step_out
 class EwnRolloutOut(C.Structure):  # struct ewn_rollout_out
     _fields_ = [("board", C.c_void_p), ("dice", C.c_void_p), ("action", C.c_void_p), ("reward", C.c_void_p),
                 ("terminated", C.c_void_p), ("truncated", C.c_void_p), ("info", C.c_void_p),
-                ("return_sum", C.c_void_p), ("n_steps", C.c_void_p), ("n_episodes", C.c_void_p), ("n_wins", C.c_void_p)]
+                ("return_sum", C.c_void_p), ("n_steps", C.c_void_p), ("n_episodes", C.c_void_p), ("n_wins", C.c_void_p),
+                ("record", C.c_void_p)]
 
 
 class EwnError(RuntimeError):
@@ -103,6 +104,7 @@ def load():
         "ewn_predict_minimax_sim": (i32, [i32, i32, i32, vp, vp, i32, u64, vp, vp, vp, vp]),
         "ewn_step_k": (i32, [cfgp, stp, i32, i32, i32, C.POINTER(EwnRolloutOut), vp]),
         "ewn_step_k_supported": (i32, [cfgp, i32, i32]),
+        "ewn_lanes_per_game": (i32, [cfgp, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -918,6 +918,26 @@ static int rollout_plan(const ewn_config *cfg, const Geom &g, const KCfg &k, int
     return EWN_OK;
 }
 
+int ewn_lanes_per_game(const ewn_config *cfg, int entry)
+{
+    Geom g; KCfg k;
+    int rc = check_cfg(cfg, g, k);
+    if (rc) return rc;
+    if (entry == 1) {
+        int T, opp, agent;
+        rc = rollout_plan(cfg, g, k, EWN_AGENT_RANDOM, 0, T, opp, agent);
+        return rc == EWN_OK ? T : 0;
+    }
+    if (entry != 0) return EWN_EINVAL;
+    const bool tab = fast_tables_bytes(g.S, g.L) > 0;
+    const bool fast = tab && cfg->opponent_kind == EWN_OPP_MINIMAX && cfg->max_depth <= 6 && fast_heur_image(cfg->heuristic) >= 0;
+    const bool lean_random = tab && cfg->opponent_kind == EWN_OPP_RANDOM;
+    if (!(fast || lean_random) || d3_threads_per_game(k.N) <= 0) return 0;
+    if (lean_random || cfg->max_depth < 3) return 1;
+    if (cfg->max_depth > 4) return (k.N <= 131072 && d3_threads_per_game(k.N) != 1) ? 2 : 1;
+    return d3_threads_per_game(k.N);
+}
+
 int ewn_step_k_supported(const ewn_config *cfg, int agent_kind, int agent_max_depth)
 {
     Geom g; KCfg k;
@@ -949,6 +969,8 @@ int ewn_step_k(const ewn_config *cfg, const ewn_state *st, int K, int agent_kind
         rb.t_board = out->board; rb.t_dice = out->dice; rb.t_action = out->action; rb.t_reward = out->reward;
         rb.t_term = out->terminated; rb.t_trunc = out->truncated; rb.t_info = out->info;
         rb.ret_sum = out->return_sum; rb.n_steps = out->n_steps; rb.n_episodes = out->n_episodes; rb.n_wins = out->n_wins;
+        rb.t_record = (uint4 *)out->record;
+        if (((uintptr_t)out->record) & 15) return EWN_EINVAL;
     }
     hipStream_t s = (hipStream_t)stream;
     switch (g.S) {

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     assert C.sizeof(EwnConfig) == 14 * 4 + 2 * 4 + 2 * 8 + 8
     assert C.sizeof(_lib.EwnState) == 7 * 8 and C.sizeof(_lib.EwnStepOut) == 7 * 8
-    assert C.sizeof(_lib.EwnRolloutOut) == 11 * 8
+    assert C.sizeof(_lib.EwnRolloutOut) == 12 * 8
 
 
 def test_step_k_availability_is_decided_on_the_host():
@@ -119,3 +119,25 @@ def test_mt_refill_queue_fits_every_lanes_per_game_choice():
             nblk = (N + gpb - 1) // gpb
             nb4 = (nblk + 3) // 4 * 4
             assert have >= 16 + 2 * nb4 * 4 + 2 * nblk * (2 * gpb) * 16, (N, T, have)
+
+
+def test_default_kernel_selection_is_not_changed_by_the_environment():
+    """EWN_D3_T / EWN_ROLLOUT_T are tuning knobs read once by the library; with neither set (as in every test and bench run) the
+    lanes-per-game choice is a function of the lane count alone, at the measured thresholds."""
+    assert "EWN_D3_T" not in os.environ and "EWN_ROLLOUT_T" not in os.environ
+    lib = _lib.load()
+    lanes = lambda entry, **kw: lib.ewn_lanes_per_game(C.byref(cfg(rng_kind=1, autoreset=1, **kw)), entry)  # noqa: E731
+    for entry in (0, 1):
+        assert lanes(entry, opponent_kind=1, n_lanes=1024) == 4
+        assert lanes(entry, opponent_kind=1, n_lanes=32767) == 4
+        assert lanes(entry, opponent_kind=1, n_lanes=32768) == 2
+        assert lanes(entry, opponent_kind=1, n_lanes=65536) == 2          # the headline configuration
+        assert lanes(entry, opponent_kind=1, n_lanes=131071) == 2
+        assert lanes(entry, opponent_kind=1, n_lanes=131072) == 1
+        assert lanes(entry, opponent_kind=0, n_lanes=65536) == 1          # RandomAgent opponent: one lane per game
+        assert lanes(entry, opponent_kind=1, max_depth=5, n_lanes=65536) == 2
+        assert lanes(entry, opponent_kind=1, max_depth=5, n_lanes=262144) == 1
+        assert lanes(entry, opponent_kind=1, heuristic=2, n_lanes=65536) == 0   # 'two_min_dist': generic kernel
+        assert lanes(entry, opponent_kind=1, board_size=7, cube_layer=4, n_lanes=65536) == 0
+    assert lanes(0, opponent_kind=1, shaped=1, n_lanes=65536) == 2 and lanes(1, opponent_kind=1, shaped=1, n_lanes=65536) == 0
+    assert lib.ewn_lanes_per_game(C.byref(cfg(n_lanes=0)), 0) == -1
