@@ -56,9 +56,6 @@ def parse():
     ap.add_argument("--steps-per-launch", type=int, default=50, help="rollout mode: env steps per ewn_step_k launch")
     ap.add_argument("--no-trajectory", action="store_true",
                     help="rollout mode: do not write the per-step trajectory (only final state and per-lane counters)")
-    ap.add_argument("--unpacked-trajectory", action="store_true",
-                    help="rollout mode: write reward / dice / flags / action as six separate [K][N] columns instead of one 16-byte "
-                         "record per lane and step")
     ap.add_argument("--agent", default="legal", choices=["legal", "uniform6"],
                     help="stand-in agent: uniformly random LEGAL action (RandomAgent), or uniform over all 6 [flag, dir] actions "
                          "(what an untrained A2C policy plays: illegal-move terminations; step mode only)")
@@ -155,7 +152,7 @@ class Runner:
         self.trajectory = trajectory
         if mode == "rollout":
             self.K = max(1, min(args.steps_per_launch, args.steps))
-            self.traj = env.alloc_rollout(self.K, packed=not args.unpacked_trajectory) if trajectory else None
+            self.traj = env.alloc_rollout(self.K) if trajectory else None
             self.kernels_per_step = 1.0 / self.K
         else:
             self.K = 1
@@ -371,8 +368,7 @@ def main():
                         "event pair on the launch stream around the timed region / launches" + note}
         if mode == "rollout":
             launch = "ewn_step_k: %d env steps per launch, %s; %s" % (
-                runner.K, ("per-step trajectory (observation + one 16-byte record of action, reward, dice, flags) written to HBM" if not args.unpacked_trajectory
-                 else "per-step trajectory (obs, action, reward, flags as separate columns) written to HBM") if runner.trajectory else "no trajectory output",
+                runner.K, "per-step trajectory (obs, action, reward, flags) written to HBM" if runner.trajectory else "no trajectory output",
                 "hipGraph replay" if not args.no_graph else "eager")
         else:
             launch = "one ewn_step launch per env step; " + ("hipGraph replay (%s)" % ", ".join("%d x %d steps" % (r, g) for g, r in runner.plan(args.steps))

@@ -53,8 +53,7 @@ class EwnStepOut(C.Structure):  # struct ewn_step_out
 class EwnRolloutOut(C.Structure):  # struct ewn_rollout_out
     _fields_ = [("board", C.c_void_p), ("dice", C.c_void_p), ("action", C.c_void_p), ("reward", C.c_void_p),
                 ("terminated", C.c_void_p), ("truncated", C.c_void_p), ("info", C.c_void_p),
-                ("return_sum", C.c_void_p), ("n_steps", C.c_void_p), ("n_episodes", C.c_void_p), ("n_wins", C.c_void_p),
-                ("record", C.c_void_p)]
+                ("return_sum", C.c_void_p), ("n_steps", C.c_void_p), ("n_episodes", C.c_void_p), ("n_wins", C.c_void_p)]
 
 
 class EwnError(RuntimeError):

@@ -969,8 +969,6 @@ int ewn_step_k(const ewn_config *cfg, const ewn_state *st, int K, int agent_kind
         rb.t_board = out->board; rb.t_dice = out->dice; rb.t_action = out->action; rb.t_reward = out->reward;
         rb.t_term = out->terminated; rb.t_trunc = out->truncated; rb.t_info = out->info;
         rb.ret_sum = out->return_sum; rb.n_steps = out->n_steps; rb.n_episodes = out->n_episodes; rb.n_wins = out->n_wins;
-        rb.t_record = (uint4 *)out->record;
-        if (((uintptr_t)out->record) & 15) return EWN_EINVAL;
     }
     hipStream_t s = (hipStream_t)stream;
     switch (g.S) {

@@ -40,7 +40,6 @@ struct RollBuf {
     int8_t *t_board; int8_t *t_dice; int8_t *t_action; double *t_reward; uint8_t *t_term; uint8_t *t_trunc; uint8_t *t_info;
     // per-lane accumulators, each may be NULL
     double *ret_sum; int32_t *n_steps; int32_t *n_episodes; int32_t *n_wins;
-    uint4 *t_record;           // [K][N] ewn_step_record, or NULL
 };
 
 // The position seen from the other side: sides swapped, every square rotated by 180 degrees (opponent_action's
@@ -207,11 +206,6 @@ __global__ __launch_bounds__(D3_BS) void k_rollout_d3(RollCfg c, RollBuf B)
             if (B.t_term) B.t_term[o] = (uint8_t)term;
             if (B.t_trunc) B.t_trunc[o] = (uint8_t)trunc;
             if (B.t_info) B.t_info[o] = (uint8_t)info;
-            if (B.t_record) { // one 16-byte store per game: consecutive writer lanes write consecutive records
-                const u64 rb = (u64)__double_as_longlong(reward);
-                const u32 w2 = (u32)(uint8_t)dice | ((u32)term << 8) | ((u32)trunc << 16) | ((u32)info << 24);
-                B.t_record[o] = make_uint4((u32)rb, (u32)(rb >> 32), w2, (u32)(uint8_t)aflag | ((u32)(uint8_t)adir << 8));
-            }
         }
         if (want_board) {
             // A wave's games are one contiguous, 16-byte aligned span of LDS (64 / T games x S*S bytes): the wave copies its own

@@ -148,18 +148,9 @@ class VecEWN:
             return False
         return self.lib.ewn_step_k_supported(C.byref(self.cfg), AGENT[agent], int(agent_max_depth)) == 1
 
-    def alloc_rollout(self, K, board=True, packed=False):
-        """Trajectory buffers for rollout(K, traj=...): dict of [K, N, ...] tensors (the observation column is optional).
-        packed=True: ONE 16-byte record per lane and step (struct ewn_step_record: one store per game instead of six); the
-        dict then holds the record tensor and the same column names as VIEWS into it."""
+    def alloc_rollout(self, K, board=True):
+        """Trajectory buffers for rollout(K, traj=...): dict of [K, N, ...] tensors (the observation column is optional)"""
         dev, N, S = self.device, self.N, self.S
-        if packed:
-            rec = torch.zeros((K, N, 16), dtype=torch.uint8, device=dev)
-            t = {"record": rec, "reward": rec[..., :8].view(torch.float64).squeeze(-1), "dice": rec[..., 8].view(torch.int8),
-                 "terminated": rec[..., 9], "truncated": rec[..., 10], "info": rec[..., 11], "action": rec[..., 12:14].view(torch.int8)}
-            if board:
-                t["board"] = torch.zeros((K, N, S, S), dtype=torch.int8, device=dev)
-            return t
         t = {"dice": torch.zeros((K, N), dtype=torch.int8, device=dev),
              "action": torch.zeros((K, N, 2), dtype=torch.int8, device=dev),
              "reward": torch.zeros((K, N), dtype=torch.float64, device=dev),
@@ -182,10 +173,10 @@ class VecEWN:
         traj, totals = traj or {}, totals or {}
         for v in traj.values():
             assert v.shape[0] >= K and v.shape[1] == self.N
-        col = (lambda name: None) if "record" in traj else (lambda name: _ptr(traj.get(name)))   # packed: the columns are views of the record
-        out = EwnRolloutOut(_ptr(traj.get("board")), col("dice"), col("action"), col("reward"), col("terminated"), col("truncated"),
-                            col("info"), _ptr(totals.get("return_sum")), _ptr(totals.get("n_steps")), _ptr(totals.get("n_episodes")),
-                            _ptr(totals.get("n_wins")), _ptr(traj.get("record")))
+        out = EwnRolloutOut(_ptr(traj.get("board")), _ptr(traj.get("dice")), _ptr(traj.get("action")), _ptr(traj.get("reward")),
+                            _ptr(traj.get("terminated")), _ptr(traj.get("truncated")), _ptr(traj.get("info")),
+                            _ptr(totals.get("return_sum")), _ptr(totals.get("n_steps")), _ptr(totals.get("n_episodes")),
+                            _ptr(totals.get("n_wins")))
         check(self.lib.ewn_step_k(C.byref(self.cfg), C.byref(self._st), int(K), AGENT[agent], int(agent_max_depth), C.byref(out),
                                   _stream()), "ewn_step_k")
         return self.board, self.dice

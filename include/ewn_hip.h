@@ -179,16 +179,6 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
                                of ewn_step_out.random_action, same stream */
 #define EWN_AGENT_MINIMAX 1 /* ExpectiMinimaxAgent(agent_max_depth, 'hybrid').predict (classical_policies/minimax.py:89-93) */
 
-/* One step of one lane as a single 16-byte record (ewn_rollout_out.record): the same values as the separate columns, laid out so
- * that a step is ONE 16-byte store per game (the six small columns cost six store instructions per wave and step). */
-typedef struct ewn_step_record {
-    double reward;
-    int8_t dice;          /* observation "dice_roll" after the step */
-    uint8_t terminated, truncated, info;
-    int8_t action[2];     /* the action the agent played at this step */
-    uint8_t pad[2];       /* zero */
-} ewn_step_record;
-
 typedef struct ewn_rollout_out {
     /* trajectory, row k = step k of this call; every pointer may be NULL (that column is not written) */
     int8_t *board;       /* [K][N][S*S] observation after step k (after the auto-reset, like ewn_state.board after ewn_step) */
@@ -203,7 +193,6 @@ typedef struct ewn_rollout_out {
     int32_t *n_steps;    /* [N] steps played (a finished, un-reset lane plays none) */
     int32_t *n_episodes; /* [N] episodes finished */
     int32_t *n_wins;     /* [N] of which won ("You won!", envs/ewn.py:454) */
-    ewn_step_record *record; /* [K][N] all of the above except the board in one record per step (16-byte aligned), or NULL */
 } ewn_rollout_out;
 
 /* Introspection: how many lanes of a wavefront share one game in the table-driven kernel this configuration runs -- entry 0:

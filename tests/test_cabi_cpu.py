@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     assert C.sizeof(EwnConfig) == 14 * 4 + 2 * 4 + 2 * 8 + 8
     assert C.sizeof(_lib.EwnState) == 7 * 8 and C.sizeof(_lib.EwnStepOut) == 7 * 8
-    assert C.sizeof(_lib.EwnRolloutOut) == 12 * 8
+    assert C.sizeof(_lib.EwnRolloutOut) == 11 * 8
 
 
 def test_step_k_availability_is_decided_on_the_host():

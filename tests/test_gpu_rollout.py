@@ -172,25 +172,3 @@ def test_tournament_through_rollouts_matches_the_reference_goldens(golden):
         assert r["lengths"].cpu().tolist() == rec["lengths"]
         slow = evaluate({"kind": "minimax", "max_depth": rec["agent_depth"]}, opp, num=len(rec["scores"]), rng="mt19937", use_rollout=False)
         assert slow["engine"] == "ewn_step" and torch.equal(slow["scores"], r["scores"]) and torch.equal(slow["lengths"], r["lengths"])
-
-
-def test_packed_step_records_equal_the_separate_columns(ea):
-    """ewn_rollout_out.record: one 16-byte ewn_step_record per lane and step carries exactly what the six separate columns do"""
-    N, K = 40000, 7
-    kw = dict(opponent_policy="minimax", max_depth=3, rng="philox", philox_key=5, autoreset=True, seed_stride=N)
-    seeds = (np.arange(N, dtype=np.uint64) + 77).astype(np.uint32)
-    a, b = ea.VecEWN(N, **kw), ea.VecEWN(N, **kw)
-    a.reset(seeds=seeds)
-    b.reset(seeds=seeds)
-    ta, tb = a.alloc_rollout(K), b.alloc_rollout(K, packed=True)
-    for _ in range(2):
-        a.rollout(K, traj=ta)
-        b.rollout(K, traj=tb)
-        for key in ("board", "dice", "action", "reward", "terminated", "truncated", "info"):
-            assert torch.equal(ta[key], tb[key].contiguous()), key
-        assert int(tb["record"][..., 14:].sum()) == 0
-    assert torch.equal(a.board, b.board) and torch.equal(a.rng_state, b.rng_state)
-    with pytest.raises(AssertionError):   # a record buffer that is not 16-byte aligned is refused on the host
-        bad = dict(tb)
-        bad["record"] = torch.zeros(K * N * 16 + 8, dtype=torch.uint8, device="cuda")[8:].view(K, N, 16)
-        b.rollout(K, traj=bad)
