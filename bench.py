@@ -140,6 +140,42 @@ def pmc_key(mode, opponent, max_depth, rng, board_size, lanes, steps_per_launch,
     return key
 
 
+class HipGraph:
+    """A hipGraph captured, instantiated, UPLOADED and launched through the HIP runtime directly (ctypes on the libamdhip64 the
+    process already has).  torch.cuda.CUDAGraph has no upload call, so the first replay of a fresh graph pays for it inside the
+    timed region (~35 us measured, tools/sync_latency.py: noticeable when the region is one 20-step launch).  Only for launch
+    sequences made of this engine's C-ABI calls (no torch operator, hence no allocator, is involved in the capture)."""
+
+    def __init__(self, torch, fn):
+        import ctypes as C
+        import re
+        libs = sorted(set(re.findall(r"(/\S*libamdhip64[^\s]*)", open("/proc/self/maps").read())), key=lambda p: ("torch" not in p, p))
+        self.hip = C.CDLL(libs[0])
+        self.torch, self.C = torch, C
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        graph, self.exe = C.c_void_p(), C.c_void_p()
+        with torch.cuda.stream(side):
+            self._ck(self.hip.hipStreamBeginCapture(C.c_void_p(side.cuda_stream), 2), "hipStreamBeginCapture")   # 2 = relaxed
+            try:
+                fn()
+            finally:
+                rc = self.hip.hipStreamEndCapture(C.c_void_p(side.cuda_stream), C.byref(graph))
+            self._ck(rc, "hipStreamEndCapture")
+        self._ck(self.hip.hipGraphInstantiate(C.byref(self.exe), graph, None, None, C.c_size_t(0)), "hipGraphInstantiate")
+        self.hip.hipGraphDestroy(graph)
+        cur = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self._ck(self.hip.hipGraphUpload(self.exe, cur), "hipGraphUpload")
+        torch.cuda.synchronize()
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed (hipError %d)" % (what, rc))
+
+    def replay(self):
+        self._ck(self.hip.hipGraphLaunch(self.exe, self.C.c_void_p(self.torch.cuda.current_stream().cuda_stream)), "hipGraphLaunch")
+
+
 class Runner:
     """One way of advancing `env` by env steps, captured into hipGraphs so that the timed region contains nothing but replays."""
 
@@ -169,6 +205,7 @@ class Runner:
                 self.gen.manual_seed(2024 + env.cfg.lane_offset)
                 self.scale = torch.tensor([2.0, 3.0], device="cuda")
         self.graphs = {}
+        self.graph_kind = "hipGraph (torch.cuda.CUDAGraph)"
 
     def launch(self, n_steps):
         """enqueue n_steps env steps"""
@@ -203,6 +240,13 @@ class Runner:
 
     def graph(self, n_steps):
         torch = self.torch
+        if n_steps not in self.graphs and self.mode == "rollout":
+            torch.cuda.synchronize()
+            try:      # captured, instantiated and uploaded ahead of the timed region
+                self.graphs[n_steps] = HipGraph(torch, lambda: self.launch(n_steps))
+                self.graph_kind = "hipGraph (captured and uploaded through the HIP runtime)"
+            except Exception as exc:
+                print("note: direct hipGraph path unavailable (%r); using torch.cuda.CUDAGraph" % (exc,), file=sys.stderr)
         if n_steps not in self.graphs:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -341,7 +385,7 @@ def main():
         kms = ev_ms / launches                                   # per ewn_step / ewn_step_k launch (launch gaps included)
         algo = N * bytes_per * steps_per_launch
         achieved = algo / (kms * 1e-3) / 1e9
-        traffic = valu = None
+        traffic = valu = rocprof_ms = None
         note = ""
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
@@ -350,6 +394,7 @@ def main():
                 ent = pmc.get(pmc_key(mode, args.opponent, args.max_depth, args.rng, args.board_size, N, runner.K, runner.trajectory))
                 if ent and pmc.get("source_hash") == source_hash():
                     traffic = ent["hbm_bytes_per_launch"]
+                    rocprof_ms = ent.get("rocprof_avg_us", 0.0) / 1e3 or None
                     vi, peak = ent.get("valu_wave_insts_per_launch"), pmc.get("valu_issue_peak_per_s")
                     if vi and peak:
                         valu = {"wave_insts_per_launch": vi, "achieved_per_s": vi / (kms * 1e-3), "peak_per_s": peak,
@@ -363,13 +408,14 @@ def main():
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "valu_issue": valu,
                 "kernel": "k_rollout_d3 (K fused env steps per launch)" if mode == "rollout" else "k_step (fused agent move + opponent search + reply + auto-reset)",
-                "kernel_ms": kms, "env_steps_per_launch": steps_per_launch, "algorithmic_bytes_per_launch": algo,
+                "kernel_ms": kms, "kernel_ms_rocprof": rocprof_ms, "env_steps_per_launch": steps_per_launch, "algorithmic_bytes_per_launch": algo,
                 "note": "integer/fp64-compare search work: VALU-bound, far from the HBM roof by construction (SURVEY 8d); kernel_ms = one HIP "
-                        "event pair on the launch stream around the timed region / launches" + note}
+                        "event pair on the launch stream around the timed region / launches; kernel_ms_rocprof = rocprofv3 --kernel-trace --stats average of the same "
+                        "kernel at this launch shape (profiles/pmc_traffic.json, same kernel sources)" + note}
         if mode == "rollout":
             launch = "ewn_step_k: %d env steps per launch, %s; %s" % (
                 runner.K, "per-step trajectory (obs, action, reward, flags) written to HBM" if runner.trajectory else "no trajectory output",
-                "hipGraph replay" if not args.no_graph else "eager")
+                runner.graph_kind + " replay" if not args.no_graph else "eager")
         else:
             launch = "one ewn_step launch per env step; " + ("hipGraph replay (%s)" % ", ".join("%d x %d steps" % (r, g) for g, r in runner.plan(args.steps))
                                                              if not args.no_graph else "eager")

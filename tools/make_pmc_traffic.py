@@ -47,7 +47,12 @@ def main():
     src, dst = sys.argv[1], sys.argv[2]
     os.makedirs(dst, exist_ok=True)
     from bench import pmc_key
-    out = {"source_hash": source_hash()}
+    import subprocess
+    try:
+        head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"]).decode().strip()
+    except Exception:
+        head = None
+    out = {"source_hash": source_hash(), "git_head_when_summarised": head}
     mixp = os.path.join(dst, "isa_mix.json")
     probe = os.path.join(dst, "valu_probe.json")
     cfgs = (("rollout_k50", "k_rollout_d3", pmc_key("rollout", "minimax", 3, "philox", 5, 65536, 50, True), 50),
