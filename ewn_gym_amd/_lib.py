@@ -108,7 +108,7 @@ def load():
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.ewn_abi_version() != 1:
+    if lib.ewn_abi_version() != 2:
         raise EwnError("libewn_hip.so ABI version mismatch")
     _lib = lib
     return lib

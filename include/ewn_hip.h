@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EWN_ABI_VERSION 1
+#define EWN_ABI_VERSION 2 /* 2: ewn_step_k, ewn_predict_minimax_sim, ewn_lanes_per_game; six table images; boards up to 11x11 */
 
 /* error codes */
 #define EWN_OK 0
