@@ -69,9 +69,13 @@ struct FastTab {
 
 // table images per board size: [heuristic image][variant]; heuristic images: 'hybrid', 'min_dist', 'attk' (functions of each side's
 // (level, count); 'two_min_dist' needs the second-nearest cube as well and stays on the generic kernels)
-#define FAST_HEUR_IMAGES 3
-EWN_DEV int fast_heur_image_dev(int heur) { return heur == 0 ? 0 : (heur == 1 ? 1 : 2); }
-static inline int fast_heur_image(int heur) { return heur == 0 ? 0 : (heur == 1 ? 1 : (heur == 3 ? 2 : -1)); }
+// The fourth image serves 'two_min_dist' (sum of each side's two smallest distances, envs/minimax_ewn.py:133-178): a side's index is
+// that SUM (0 .. 2(S-1)) instead of (level, count), the image's `lvl` table holds distances instead of levels, and the search
+// looks at a mask's two highest bits (template parameter H2 of d3_search / d5_search: the lane-sharing step and rollout kernels
+// are not instantiated with it; the stateless predict kernel and the one-thread-per-game step kernel are).
+#define FAST_HEUR_IMAGES 4
+static inline int fast_heur_image(int heur) { return heur == 0 ? 0 : (heur == 1 ? 1 : (heur == 3 ? 2 : (heur == 2 ? 3 : -1))); }
+static inline bool fast_heur_lean(int heur) { return heur == 0 || heur == 1 || heur == 3; } // images k_step_d3 / k_rollout_d3 can run
 
 // LDS / device image size: the struct padded to 4 KiB so the LDS-DMA copy needs no tail handling
 #define FAST_TAB_BYTES(S) ((int)((sizeof(FastTab<S>) + 4095) / 4096 * 4096))
@@ -102,6 +106,18 @@ EWN_DEV int lvl_index(u32 m) { return clz_nz(m); }
 EWN_DEV int lvl_index(u64 m) { return clz_m(m); }
 // one side's 6-bit (level, count) index: one byte read + v_bcnt_u32_b32 with its accumulate operand
 template <int S> EWN_DEV u32 ft_side(const FastTab<S> *Tb, typename MaskOf<S>::type m) { return (u32)Tb->lvl[lvl_index(m)] + (u32)popc_m(m); }
+// 'two_min_dist' image: the side's index is the sum of the distances of its two highest cells (one cell: its distance alone;
+// none: 0, the row that answers -10)
+EWN_DEV u32 drop_top(u32 m) { return m ? m & ~(0x80000000u >> __clz((int)m)) : 0u; }
+EWN_DEV u64 drop_top(u64 m) { return m ? m & ~(0x8000000000000000ull >> __clzll((long long)m)) : 0ull; }
+template <int S> EWN_DEV u32 ft_side2(const FastTab<S> *Tb, typename MaskOf<S>::type m)
+{
+    return (u32)Tb->lvl[lvl_index(m)] + (u32)Tb->lvl[lvl_index(drop_top(m))];
+}
+template <int S, bool H2> EWN_DEV u32 ft_side_h(const FastTab<S> *Tb, typename MaskOf<S>::type m)
+{
+    if constexpr (H2) return ft_side2<S>(Tb, m); else return ft_side<S>(Tb, m);
+}
 // byte address of a leaf's entry inside rank[]
 EWN_DEV u32 ft_addr(u32 ix, u32 iy) { return (ix << 7) | (iy << 1); }
 template <int S> EWN_DEV u32 ft_rank8(const FastTab<S> *Tb, u32 addr) { return *(const uint16_t *)((const char *)Tb->rank + addr); }
@@ -183,13 +199,24 @@ static int build_fast_tables(FastTab<S> *T, int variant = 0, int heur = 0)
     const int W = S <= 5 ? 32 : 64;
     for (int z = 0; z <= W; z++) {
         const int h = W - 1 - z; // highest set bit
-        const int t = (z == W || h >= S * S) ? 0 : level_of_ring[h];
-        T->lvl[z] = (uint8_t)(t << 3);
+        const bool none = z == W || h >= S * S;
+        const int t = none ? 0 : level_of_ring[h];
+        T->lvl[z] = heur == 2 ? (uint8_t)(none ? 0 : S - 1 - t) : (uint8_t)(t << 3); // 'two_min_dist': the distance itself
     }
     // leaf values: score = 0; score += (L - mdP) * (1 / nP); score -= (L - mdN) * (1 / nN)   (envs/minimax_ewn.py:79-82)
     // with L = S, md = S - 1 - t.  volatile keeps every rounding step a separate fp64 operation.
     std::vector<double> all;
     std::vector<double> e((size_t)IXN * IXN, 0.0);
+    std::vector<char> used_e((size_t)IXN * IXN, 0);
+    if (heur == 2) { // index = sum of the two smallest distances of a side, 1 .. 2(S-1); value = sum(BOTTOM_RIGHT) - sum(TOP_LEFT), :176
+        for (int sp = 1; sp <= 2 * (S - 1); sp++)
+            for (int sn = 0; sn <= 2 * (S - 1); sn++) { // 0: BOTTOM_RIGHT's only cube still sits on the far corner (both sides are measured to it)
+                double ev = (double)(sn - sp);
+                if (variant == 1) { volatile double sixth = ev / 6.0, acc = 0.0; for (int d = 0; d < 6; d++) acc = acc + sixth; ev = acc; }
+                e[(size_t)sp * IXN + sn] = ev; used_e[(size_t)sp * IXN + sn] = 1;
+                all.push_back(ev);
+            }
+    } else
     for (int tp = 0; tp < S; tp++) for (int np_ = 1; np_ <= 6; np_++)
         for (int tn = 0; tn < S; tn++) for (int nn = 1; nn <= 6; nn++) {
             volatile double rp = 1.0 / (double)np_, rn_ = 1.0 / (double)nn;
@@ -202,7 +229,7 @@ static int build_fast_tables(FastTab<S> *T, int variant = 0, int heur = 0)
             if (heur == 1) ev = (double)((tp + 1) - (tn + 1));
             if (heur == 3) ev = (double)(-(np_ + nn));
             if (variant == 1) { volatile double sixth = ev / 6.0, acc = 0.0; for (int d = 0; d < 6; d++) acc = acc + sixth; ev = acc; }
-            e[(size_t)(tp * 8 + np_) * IXN + (tn * 8 + nn)] = ev;
+            e[(size_t)(tp * 8 + np_) * IXN + (tn * 8 + nn)] = ev; used_e[(size_t)(tp * 8 + np_) * IXN + (tn * 8 + nn)] = 1;
             all.push_back(ev);
         }
     all.push_back(-10.0);
@@ -221,7 +248,7 @@ static int build_fast_tables(FastTab<S> *T, int variant = 0, int heur = 0)
     const uint16_t m10 = (uint16_t)(1 + (std::lower_bound(all.begin(), all.end(), -10.0) - all.begin()));
     for (int ix = 0; ix < IXN; ix++)
         for (int iy = 0; iy < IXN; iy++) {
-            const bool used = (ix % 8) >= 1 && (ix % 8) <= 6 && (iy % 8) >= 1 && (iy % 8) <= 6 && ix / 8 < S && iy / 8 < S;
+            const bool used = used_e[(size_t)ix * IXN + iy] != 0;
             // a slot no position maps to (count 0 = the side has lost its last cube, envs/minimax_ewn.py:45-47) answers -10
             T->rank[ix * IXN + iy] = (uint16_t)(8 * (used ? (uint16_t)(1 + (std::lower_bound(all.begin(), all.end(), e[(size_t)ix * IXN + iy]) - all.begin())) : m10));
         }

@@ -250,7 +250,8 @@ __global__ __launch_bounds__(BS) void k_step(Geom g, KCfg c, KState st, const in
                 } else if (reply) {
                     if constexpr (FAST != 0) {
                         const GState<1> cst = canonicalize<1>(g, s);
-                        fast_d3<(FAST ? FAST : 5)>(ftab, cst, dice, c.depth, oflag, odir);
+                        if (c.heur == EWN_H_TWO_MIN_DIST) fast_d3<(FAST ? FAST : 5), true>(ftab, cst, dice, c.depth, oflag, odir);
+                        else fast_d3<(FAST ? FAST : 5), false>(ftab, cst, dice, c.depth, oflag, odir);
                     } else if (PHASE == 0) {
                         if (c.opp == EWN_OPP_RANDOM) policy_random<NW>(g, s, dice, r, oflag, odir);
                         else policy_minimax_rt<NW>(g, s, dice, c.depth, c.heur, oflag, odir);
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(BS) void k_predict_minimax(Geom g, int M, const int
     if (values) values[m] = v;
 }
 
-template <int S>
+template <int S, bool H2>
 __global__ __launch_bounds__(BS) void k_predict_minimax_fast(Geom g, int M, const int8_t *boards, const int8_t *dice, int depth,
                                                              int8_t *actions, double *values, const void *tables)
 {
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(BS) void k_predict_minimax_fast(Geom g, int M, cons
     const int dc = dice[m];
     if (s.aliveP != 0 && dc >= 1 && dc <= g.CN) {
         if (is_win<1>(g, s)) v = evaluate<1>(g, s, EWN_H_HYBRID);
-        else v = fast_d3<S>(T, s, dc, depth, f, d);
+        else v = fast_d3<S, H2>(T, s, dc, depth, f, d);
     }
     actions[2 * m] = (int8_t)f; actions[2 * m + 1] = (int8_t)d;
     if (values) values[m] = v;
@@ -725,7 +726,7 @@ int ewn_build_tables(int board_size, int cube_layer, void *host_out)
     if (!host_out) return EWN_ENULL;
     if (ewn_tables_bytes(board_size, cube_layer) <= 0) return EWN_EUNSUPPORTED;
     int rc = 0;
-    static const int heur_of_image[FAST_HEUR_IMAGES] = { EWN_H_HYBRID, EWN_H_MIN_DIST, EWN_H_ATTK };
+    static const int heur_of_image[FAST_HEUR_IMAGES] = { EWN_H_HYBRID, EWN_H_MIN_DIST, EWN_H_ATTK, EWN_H_TWO_MIN_DIST };
     for (int hi = 0; hi < FAST_HEUR_IMAGES; hi++)
         for (int variant = 0; variant < 2; variant++) {
             void *dst = (int8_t *)host_out + (size_t)(hi * 2 + variant) * fast_tables_bytes(board_size, cube_layer);
@@ -849,7 +850,7 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
                           cfg->max_depth <= 6 && fast_heur_image(cfg->heuristic) >= 0;
         const bool lean_random = st->tables && fast_tables_bytes(g.S, g.L) > 0 && cfg->opponent_kind == EWN_OPP_RANDOM;
         if (fast) ks.tables = fast_image(st->tables, g.S, g.L, cfg->max_depth, cfg->heuristic); // the image of this heuristic and depth class
-        if ((fast || lean_random) && d3_threads_per_game(k.N) > 0) {
+        if (((fast && fast_heur_lean(cfg->heuristic)) || lean_random) && d3_threads_per_game(k.N) > 0) {
             // the lean fused kernel: canonical ring space end to end, T lanes per game (ewn_step_d3.hpp / ewn_step_d3.hip).
             // MT kind with auto-reset: window refills are extra blocks of the same launch (needs the caller's scratch).
             const bool fused_refill = refill && scratch != nullptr;
@@ -899,7 +900,7 @@ static int rollout_plan(const ewn_config *cfg, const Geom &g, const KCfg &k, int
 {
     if (fast_tables_bytes(g.S, g.L) <= 0 || cfg->shaped) return EWN_EUNSUPPORTED;
     if (cfg->opponent_kind == EWN_OPP_RANDOM) opp = 1;
-    else if (cfg->opponent_kind == EWN_OPP_MINIMAX && fast_heur_image(cfg->heuristic) >= 0) opp = cfg->max_depth > 4 ? 2 : 0;
+    else if (cfg->opponent_kind == EWN_OPP_MINIMAX && fast_heur_lean(cfg->heuristic)) opp = cfg->max_depth > 4 ? 2 : 0;
     else return EWN_EUNSUPPORTED;
     if (agent_kind == EWN_AGENT_RANDOM) agent = 0;
     else if (agent_kind == EWN_AGENT_MINIMAX) {
@@ -930,7 +931,7 @@ int ewn_lanes_per_game(const ewn_config *cfg, int entry)
     }
     if (entry != 0) return EWN_EINVAL;
     const bool tab = fast_tables_bytes(g.S, g.L) > 0;
-    const bool fast = tab && cfg->opponent_kind == EWN_OPP_MINIMAX && cfg->max_depth <= 6 && fast_heur_image(cfg->heuristic) >= 0;
+    const bool fast = tab && cfg->opponent_kind == EWN_OPP_MINIMAX && cfg->max_depth <= 6 && fast_heur_lean(cfg->heuristic);
     const bool lean_random = tab && cfg->opponent_kind == EWN_OPP_RANDOM;
     if (!(fast || lean_random) || d3_threads_per_game(k.N) <= 0) return 0;
     if (lean_random || cfg->max_depth < 3) return 1;
@@ -1073,12 +1074,15 @@ int ewn_predict_minimax(int board_size, int cube_layer, int M, const int8_t *boa
     }
     if (tables && fast_tables_bytes(g.S, g.L) > 0 && max_depth <= 6 && fast_heur_image(heuristic) >= 0) {
         tables = fast_image(tables, g.S, g.L, max_depth, heuristic);
+#define PMF(SS) do { if (heuristic == EWN_H_TWO_MIN_DIST) k_predict_minimax_fast<SS, true><<<GRID(M), BS, FAST_TAB_BYTES(SS), s>>>(g, M, boards, dice, max_depth, actions, values, tables); \
+                    else k_predict_minimax_fast<SS, false><<<GRID(M), BS, FAST_TAB_BYTES(SS), s>>>(g, M, boards, dice, max_depth, actions, values, tables); } while (0)
         switch (g.S) {
-        case 5: k_predict_minimax_fast<5><<<GRID(M), BS, FAST_TAB_BYTES(5), s>>>(g, M, boards, dice, max_depth, actions, values, tables); break;
-        case 6: k_predict_minimax_fast<6><<<GRID(M), BS, FAST_TAB_BYTES(6), s>>>(g, M, boards, dice, max_depth, actions, values, tables); break;
-        case 7: k_predict_minimax_fast<7><<<GRID(M), BS, FAST_TAB_BYTES(7), s>>>(g, M, boards, dice, max_depth, actions, values, tables); break;
-        default: k_predict_minimax_fast<8><<<GRID(M), BS, FAST_TAB_BYTES(8), s>>>(g, M, boards, dice, max_depth, actions, values, tables); break;
+        case 5: PMF(5); break;
+        case 6: PMF(6); break;
+        case 7: PMF(7); break;
+        default: PMF(8); break;
         }
+#undef PMF
         return launch_status();
     }
     BY_NW(g, launch_minimax<NWV>(g, M, boards, dice, max_depth, heuristic, actions, values, s));

@@ -108,7 +108,7 @@ EWN_DEV void rs_move(RState<S> &s, int k, int q)
 // byte-per-cube state and the table leaf.  One lane per game; breaks diverge between the lanes of a wave, trip counts are
 // bounded (6^5 leaves).  A leaf is a rank lookup, an inner node a masked move: ~20x fewer instructions than the generic
 // template recursion on GState.
-template <int S, int T = 1>
+template <int S, int T = 1, bool H2 = false>
 __device__ __forceinline__ double d5_search(const FastTab<S> *Tb, const RState<S> &c, int dice, int sub, int &bflag, int &bdir)
 {
     static_assert(T == 1 || T == 2, "the six dice of the inner chance node are split over one or two lanes");
@@ -166,8 +166,8 @@ __device__ __forceinline__ double d5_search(const FastTab<S> *Tb, const RState<S
                                 const M bd = ex[m] ? (one << (dp & 63)) : (M)0;
                                 const M P3 = (s2.P & ~(one << (mb & 63))) | bd, N3 = s2.N & ~bd;
                                 won[m] = dp == FastTab<S>::CELLS - 1 || N3 == 0;          // evaluate() of a won position: +10
-                                lx[m] = ft_side<S>(Tb, P3);
-                                ly[m] = ft_side<S>(Tb, N3);
+                                lx[m] = ft_side_h<S, H2>(Tb, P3);
+                                ly[m] = ft_side_h<S, H2>(Tb, N3);
                             }
                             __builtin_amdgcn_sched_barrier(0);
                             #pragma unroll
@@ -247,7 +247,7 @@ template <int T> EWN_DEV void publish(u32 mine, int i, u32 (&out)[6])
 // v_and_or for the root-invariant exceptions; ranks travel as byte offsets (8 x rank) so that value reads need no shift either;
 // a cube's result is ONE 16-bit key (the cut-off value if its replies cut, else 0x8000 | minimum) so that the pair selection per
 // dice is a compare, a min and a select; the lanes exchange keys and chosen ranks, never doubles.
-template <int S, int T>
+template <int S, int T, bool H2 = false>
 __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S> &c, int dice, int sub, int depth, int &bflag, int &bdir)
 {
     typedef typename MaskOf<S>::type M;
@@ -278,7 +278,7 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
             const M P1 = (c.P & ~(one << rp)) | bd;
             const M N1 = c.N & ~bd;
             const bool term = dest == FastTab<S>::CELLS - 1 || N1 == 0; // win(B1): value 10 at any depth
-            const u32 rk = ft_rank8<S>(Tb, ft_addr(ft_side<S>(Tb, P1), ft_side<S>(Tb, N1)));
+            const u32 rk = ft_rank8<S>(Tb, ft_addr(ft_side_h<S, H2>(Tb, P1), ft_side_h<S, H2>(Tb, N1)));
             const double e1 = ft_val<S>(Tb, rk), e6 = ft_val6<S>(Tb, rk);
             double v = 0.0;
             #pragma unroll
@@ -346,6 +346,10 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
                     P2[ii][d] = P1 & ~rset[i0 + ii][d];
                     lp[ii][d] = Tb->lvl[lvl_index(P2[ii][d])]; // P2 == 0 (last cube captured): level 0 + count 0 = a row of -10
                     ln[ii][d] = Tb->lvl[lvl_index(N2[ii][d])]; // N2 holds the moved cube unless the reply is absent (address masked)
+                    if constexpr (H2) { // 'two_min_dist': distance of the highest cell + distance of the second highest
+                        lp[ii][d] += Tb->lvl[lvl_index(drop_top(P2[ii][d]))];
+                        ln[ii][d] += Tb->lvl[lvl_index(drop_top(N2[ii][d]))];
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -353,7 +357,7 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
             for (int ii = 0; ii < CH; ii++) {
                 #pragma unroll
                 for (int d = 0; d < 3; d++) {
-                    const u32 ix = lp[ii][d] + (u32)popc_m(P2[ii][d]), iy = ln[ii][d] + (u32)popc_m(N2[ii][d]);
+                    const u32 ix = H2 ? lp[ii][d] : lp[ii][d] + (u32)popc_m(P2[ii][d]), iy = H2 ? ln[ii][d] : ln[ii][d] + (u32)popc_m(N2[ii][d]);
                     a[ii][d] = ft_rank8<S>(Tb, (ft_addr(ix, iy) & keep[i0 + ii][d]) | fixed[i0 + ii][d]);
                 }
             }
@@ -417,7 +421,7 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
 }
 
 // The same search from a row-major canonical GState (stateless predict kernel, generic step kernel's fast path)
-template <int S>
+template <int S, bool H2 = false>
 __device__ __forceinline__ double fast_d3(const FastTab<S> *Tb, const GState<1> &c, int dice, int depth, int &bflag, int &bdir)
 {
     typedef typename MaskOf<S>::type M;
@@ -432,8 +436,8 @@ __device__ __forceinline__ double fast_d3(const FastTab<S> *Tb, const GState<1> 
         s.posP |= (u64)(ap ? rp : PK_OFF) << (8 * k);
         s.posN |= (u64)(an ? rn : PK_OFF) << (8 * k);
     }
-    if (depth >= 5) return d5_search<S, 1>(Tb, s, dice, 0, bflag, bdir);
-    return d3_search<S, 1>(Tb, s, dice, 0, depth, bflag, bdir);
+    if (depth >= 5) return d5_search<S, 1, H2>(Tb, s, dice, 0, bflag, bdir);
+    return d3_search<S, 1, H2>(Tb, s, dice, 0, depth, bflag, bdir);
 }
 
 // ---------------------------------------------------------------- the fused step kernel

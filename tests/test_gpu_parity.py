@@ -673,11 +673,13 @@ def test_no_kernel_writes_outside_its_buffers(ea, monkeypatch):
     vec_env._TABLES.update(saved_tables)
 
 
-@pytest.mark.parametrize("heur", ["min_dist", "attk"])
+@pytest.mark.parametrize("heur", ["min_dist", "attk", "two_min_dist"])
 @pytest.mark.parametrize("S,depth,n", [(5, 1, 1500), (5, 2, 1500), (5, 3, 6000), (5, 4, 400), (5, 5, 60), (7, 3, 1500), (8, 4, 200), (6, 6, 6)])
 def test_integer_heuristics_on_the_table_driven_kernel(ea, heur, S, depth, n):
     """'min_dist' and 'attk' (envs/minimax_ewn.py:88-131, 180-213) are functions of each side's (level, count) like 'hybrid':
-    the table-driven search runs them from their own table images; against the template recursion and the oracle."""
+    the table-driven search runs them from their own table images; 'two_min_dist' (:133-178) from an image indexed by each side's
+    sum of its two smallest distances (stateless predict and the one-thread-per-game step); against the template recursion and
+    the oracle, late-game positions (one or two cubes a side) included."""
     b, d = _random_positions(S, 3, n, 4000 + depth + S, max_steps=14 if S == 5 else 24)
     fa, fv = ea.predict_minimax(b, d, depth, heur, use_tables=True)
     oa, ov, _ = po.predict_minimax(b, d, depth, heur)
@@ -697,6 +699,8 @@ def test_generic_kernels_stay_covered(ea):
     _lockstep(ea, 500, 20, opponent_policy="minimax", max_depth=4, heuristic="attk", rng="mt19937")
     _lockstep(ea, 300, 20, board_size=7, opponent_policy="minimax", max_depth=3, heuristic="min_dist", rng="philox", philox_key=8)
     _lockstep(ea, 128, 10, opponent_policy="minimax", max_depth=5, heuristic="attk", rng="philox", philox_key=9)
+    _lockstep(ea, 2000, 40, opponent_policy="minimax", max_depth=3, heuristic="two_min_dist", rng="philox", philox_key=12)   # table path of the one-thread-per-game step
+    _lockstep(ea, 300, 30, board_size=7, opponent_policy="minimax", max_depth=4, heuristic="two_min_dist", rng="mt19937", shaped=True)
     _lockstep(ea, 40000, 8, shaped=True, illegal_move_tolerance=2, reward=10.0, opponent_policy="minimax", max_depth=3, rng="philox",
               philox_key=10, check_terminal=False)
 
