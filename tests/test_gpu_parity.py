@@ -650,6 +650,28 @@ def test_no_kernel_writes_outside_its_buffers(ea, monkeypatch):
             assert bool((buf[:G] == 0xA5).all()) and bool((buf[G + pad:] == 0xA5).all()), kw
         assert tables_intact(), kw
         guarded.clear()
+    # ewn_step_k: state, trajectory ([K][N] columns) and per-lane totals, every lanes-per-game choice, partial last blocks
+    for kw in (dict(n=1000, opponent_policy="minimax", max_depth=3, rng="philox"), dict(n=257, opponent_policy="random", rng="philox"),
+               dict(n=40000, opponent_policy="minimax", max_depth=3, rng="philox"), dict(n=140000, opponent_policy="minimax", max_depth=2, rng="philox"),
+               dict(n=300, opponent_policy="minimax", max_depth=5, rng="mt19937", autoreset=False, agent="minimax"),
+               dict(n=513, opponent_policy="minimax", max_depth=4, rng="philox", board_size=8, agent="minimax")):
+        kw = dict(kw)
+        n, agent, autoreset = kw.pop("n"), kw.pop("agent", "random"), kw.pop("autoreset", True)
+        monkeypatch.setattr(vec_env.torch, "zeros", guarded_zeros)
+        try:
+            env = ea.VecEWN(n, autoreset=autoreset, **kw)
+            traj, tot = env.alloc_rollout(7), env.alloc_totals()
+        finally:
+            monkeypatch.setattr(vec_env.torch, "zeros", real_zeros)
+        env.reset(seeds=np.arange(n) + 3)
+        for _ in range(3):
+            env.rollout(7, agent=agent, agent_max_depth=3, traj=traj, totals=tot)
+            env.rollout(5, agent=agent, agent_max_depth=3)
+        torch.cuda.synchronize()
+        for buf, pad in guarded:
+            assert bool((buf[:G] == 0xA5).all()) and bool((buf[G + pad:] == 0xA5).all()), kw
+        assert tables_intact(), kw
+        guarded.clear()
     # the stateless queries allocate their outputs with torch.zeros too
     for (S, L, M) in ((5, 3, 1), (5, 3, 63), (7, 3, 1000), (8, 5, 77), (6, 4, 130)):
         b, d = _random_positions(S, L, M, 900 + M, max_steps=20)
