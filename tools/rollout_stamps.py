@@ -19,7 +19,9 @@ K = int(args[0]) if args else 50
 N = 65536
 env = ea.VecEWN(N, opponent_policy="minimax", max_depth=3, rng="philox", autoreset=True, philox_key=2024, seed_stride=N)
 env.reset(seeds=np.arange(N) + 9487)
-traj = None if "--no-traj" in sys.argv else env.alloc_rollout(K)
+traj = None if "--no-traj" in sys.argv else env.alloc_rollout(K, board="--no-board" not in sys.argv)
+if traj is not None and "--only-board" in sys.argv:
+    traj = {"board": traj["board"]}
 tot = env.alloc_totals()
 for _ in range(3):
     env.rollout(K, traj=traj, totals=tot)
