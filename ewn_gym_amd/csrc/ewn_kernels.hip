@@ -223,7 +223,10 @@ __global__ __launch_bounds__(BS) void k_step(Geom g, KCfg c, KState st, const in
             if (frozen) {
                 // no reference counterpart: stepping a finished game is undefined upstream; the lane stays put
                 o.term = 1;
-                if (PHASE == 1) sc.phase[lane] = 0;
+                if (PHASE == 1) {
+                    sc.phase[lane] = 0;
+                    if (c.opp == EWN_OPP_MCTS) for (int i = 0; i < 6; i++) sc.wins[(size_t)lane * 6 + i] = -1;
+                }
                 if (out.tboard) for (int i = 0; i < g.cells; i++) mine_t[i] = mine[i];
                 if (out.tdice) out.tdice[lane] = (int8_t)dice;
                 if (out.ract) ((uint16_t *)out.ract)[lane] = 0;
@@ -240,14 +243,29 @@ __global__ __launch_bounds__(BS) void k_step(Geom g, KCfg c, KState st, const in
                 else reply = true;
                 if (PHASE == 1) {
                     sc.phase[lane] = reply ? 1 : 0;
+                    int n_root = 0;
                     if (reply) {
                         const GState<NW> cst = canonicalize<NW>(g, s);
                         encode_board<NW>(g, cst, sc.cboard + (size_t)lane * g.cells);
                         sc.cdice[lane] = (int8_t)dice;
                         sc.obs_id[lane] = r.seed_mix() * 0x9E3779B1u + r.draws();
                         settled = false;
+                        if (c.opp == EWN_OPP_MCTS) n_root = for_each_legal<0, NW>(g, cst, dice, [](int, int, int) { return true; });
                     }
+                    // flat Monte-Carlo opponent: the win counters of the root moves start here (0 = a move to play out, -1 = no
+                    // such move / no reply pending) -- what k_mcts_init does for the stateless policy, without its launch
+                    if (c.opp == EWN_OPP_MCTS) for (int i = 0; i < 6; i++) sc.wins[(size_t)lane * 6 + i] = i < n_root ? 0 : -1;
                 } else if (reply) {
+                    if (PHASE == 2 && c.opp == EWN_OPP_MCTS) {
+                        // MctsAgent's choice, classical_policies/mcts.py:68: np.argmax over the root moves' wins (first maximum),
+                        // then that entry of the legal list of the canonical observation -- k_mcts_pick without its launch
+                        int best = 0, bw = -1;
+                        for (int i = 0; i < 6; i++) { const int w = sc.wins[(size_t)lane * 6 + i]; if (w > bw) { bw = w; best = i; } }
+                        const GState<NW> cst = canonicalize<NW>(g, s);
+                        int j = 0;
+                        oflag = 0; odir = 0;
+                        for_each_legal<0, NW>(g, cst, dice, [&](int flag, int, int dir) { if (j == best) { oflag = flag; odir = dir; } j++; return j <= best; });
+                    }
                     if constexpr (FAST != 0) {
                         const GState<1> cst = canonicalize<1>(g, s);
                         if (c.heur == EWN_H_TWO_MIN_DIST) fast_d3<(FAST ? FAST : 5), true>(ftab, cst, dice, c.depth, oflag, odir);
@@ -807,17 +825,19 @@ int ewn_reset(const ewn_config *cfg, const ewn_state *st, const uint32_t *seeds,
 int ewn_predict_mcts(int board_size, int cube_layer, int M, const int8_t *boards, const int8_t *dice, int num_simulations,
                      int num_env_copies, uint64_t key, const uint32_t *obs_id, int8_t *actions, int32_t *wins, void *stream);
 
+// init_and_pick: the stateless policy (ewn_predict_mcts) needs k_mcts_init / k_mcts_pick; inside ewn_step the two half-step
+// kernels do both jobs (k_step PHASE 1 / 2), so the MCTS opponent's step is three launches: half step, playouts, half step
 static int mcts_launch(const Geom &g, int M, const int8_t *boards, const int8_t *dice, const uint8_t *active, int total, u64 key,
-                       const u32 *obs_id, int8_t *actions, int32_t *wins, hipStream_t s)
+                       const u32 *obs_id, int8_t *actions, int32_t *wins, hipStream_t s, bool init_and_pick = true)
 {
     const bool lean = g.CN <= 6 && g.S <= 8; // the byte-per-cube playout numbers cells row * 8 + col
     const int gl = playout_group_log2(total), opb = mcts_obs_per_block(gl);
     const long long threads = lean ? (((long long)M + opb - 1) / opb) * BS : (long long)M * 6 * total;
     if (threads > 0x7fffffffll * BS) return EWN_EINVAL;
-    BY_NW(g, (k_mcts_init<NWV><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, active, wins)));
+    if (init_and_pick) BY_NW(g, (k_mcts_init<NWV><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, active, wins)));
     if (lean) k_mcts_rollout_lean<<<GRID(threads), BS, 0, s>>>(g, M, total, gl, opb, boards, dice, obs_id, key, wins);
     else BY_NW(g, (k_mcts_rollout<NWV><<<GRID(threads), BS, 0, s>>>(g, M, total, boards, dice, obs_id, key, wins)));
-    BY_NW(g, (k_mcts_pick<NWV><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, wins, actions)));
+    if (init_and_pick) BY_NW(g, (k_mcts_pick<NWV><<<GRID(M), BS, 0, s>>>(g, M, boards, dice, wins, actions)));
     return launch_status();
 }
 
@@ -873,7 +893,7 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
         if (rc) return rc;
         if (sim_opp) {
             BY_NW(g, rc = launch_minimax_sim<NWV>(g, k.N, sc.cboard, sc.cdice, sc.phase, sc.obs_id, k.key, k.depth, sc.act, nullptr, s));
-        } else rc = mcts_launch(g, k.N, sc.cboard, sc.cdice, sc.phase, k.nsim_total, k.key, sc.obs_id, sc.act, sc.wins, s);
+        } else rc = mcts_launch(g, k.N, sc.cboard, sc.cdice, sc.phase, k.nsim_total, k.key, sc.obs_id, sc.act, sc.wins, s, false);
         if (rc) return rc;
         BY_NW(g, (k_step<NWV, 2, 0><<<GRID(k.N), BS, lds, s>>>(g, k, ks, actions, ko, sc)));
     }
