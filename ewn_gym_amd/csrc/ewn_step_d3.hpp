@@ -569,16 +569,27 @@ EWN_DEV void d3_encode(const FastTab<S> *Tb, const RState<S> &s, int sub, int8_t
 template <int S, int T>
 EWN_DEV void d3_encode_cubes(const FastTab<S> *Tb, const RState<S> &s, int sub, int8_t *b)
 {
-    int cell[12];
-    #pragma unroll
-    for (int k = 0; k < 6; k++) {
-        cell[2 * k] = Tb->real_of_ring[pk_get(s.posN, k) & 63];
-        cell[2 * k + 1] = Tb->real_of_ring[pk_get(s.posP, k) & 63];
-    }
-    #pragma unroll
-    for (int k = 0; k < 6; k++) {
-        if (T == 1 || (2 * k) % T == sub) if (!(pk_get(s.posN, k) & PK_OFF)) b[cell[2 * k]] = (int8_t)(k + 1);
-        if (T == 1 || (2 * k + 1) % T == sub) if (!(pk_get(s.posP, k) & PK_OFF)) b[cell[2 * k + 1]] = (int8_t)(-(k + 1));
+    // lane `sub` of the game's T lanes places the cubes whose slot number (2k: agent cube k, 2k + 1: opponent cube k) is sub mod T;
+    // for T = 2 that is one whole side per lane: six table reads and six byte stores each
+    if constexpr (T == 2) {
+        const u64 pos = sub ? s.posP : s.posN;
+        int cell[6];
+        #pragma unroll
+        for (int k = 0; k < 6; k++) cell[k] = Tb->real_of_ring[pk_get(pos, k) & 63];
+        #pragma unroll
+        for (int k = 0; k < 6; k++) if (!(pk_get(pos, k) & PK_OFF)) b[cell[k]] = (int8_t)(sub ? -(k + 1) : (k + 1));
+    } else {
+        int cell[12];
+        #pragma unroll
+        for (int k = 0; k < 6; k++) {
+            cell[2 * k] = Tb->real_of_ring[pk_get(s.posN, k) & 63];
+            cell[2 * k + 1] = Tb->real_of_ring[pk_get(s.posP, k) & 63];
+        }
+        #pragma unroll
+        for (int k = 0; k < 6; k++) {
+            if (T == 1 || (2 * k) % T == sub) if (!(pk_get(s.posN, k) & PK_OFF)) b[cell[2 * k]] = (int8_t)(k + 1);
+            if (T == 1 || (2 * k + 1) % T == sub) if (!(pk_get(s.posP, k) & PK_OFF)) b[cell[2 * k + 1]] = (int8_t)(-(k + 1));
+        }
     }
 }
 
