@@ -110,17 +110,28 @@ class EinsteinWuerfeltNichtEnv(_Base):
 
     def step(self, action):
         """envs/ewn.py:436-486 -> (obs, reward, terminated, truncated, info)"""
+        import torch
         import ewn_gym_amd
         a = np.asarray(action).reshape(-1)
-        _, _, r, te, tr, info = self._engine.step(np.array([[int(a[0]), int(a[1])]], dtype=np.int8))
-        self._pull()
-        code = int(info[0].item())
-        self._engine.check_rng()      # an episode longer than the MT19937-compat stream supports must not pass silently
+        e = self._engine
+        _, _, r, te, tr, info = e.step(np.array([[int(a[0]), int(a[1])]], dtype=np.int8))
+        # ONE device-to-host copy (and one synchronisation) for everything the caller gets back: board, dice, reward, the three
+        # flags, the remaining tolerance (shaped env) and the MT-stream overflow flag
+        S2 = self.board.size
+        tol = e.tolerance if e.tolerance is not None else torch.zeros(1, dtype=torch.int32, device=e.device)
+        packed = torch.cat([e.board.reshape(-1).view(torch.uint8), e.dice.view(torch.uint8), te, tr, info, e.rng_overflow(),
+                            r.view(torch.uint8), tol.view(torch.uint8)]).cpu().numpy()
+        self.board[:] = packed[:S2].view(np.int8).reshape(self.board.shape)   # in place: obs["board"] aliases env state upstream too
+        self.dice_roll = int(packed[S2:S2 + 1].view(np.int8)[0])
+        terminated, truncated, code, overflow = (int(x) for x in packed[S2 + 1:S2 + 5])
+        reward = float(packed[S2 + 5:S2 + 13].view(np.float64)[0])
+        if overflow:
+            e.check_rng()             # raises: an episode longer than the MT19937-compat stream supports must not pass silently
         msg = ewn_gym_amd.INFO_MESSAGES[code]
         if code == 5:
-            msg = msg.format(int(self._engine.tolerance[0].item()))
+            msg = msg.format(int(packed[S2 + 13:S2 + 17].view(np.int32)[0]))
         self.current_player = Player.BOTTOM_RIGHT if code in (3, 4) else Player.TOP_LEFT
-        return self._obs(), float(r[0].item()), bool(te[0].item()), bool(tr[0].item()), ({"message": msg} if msg else {})
+        return self._obs(), reward, bool(terminated), bool(truncated), ({"message": msg} if msg else {})
 
     def roll_dice(self):
         raise NotImplementedError("dice are rolled on the device inside reset()/step()")
