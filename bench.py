@@ -175,6 +175,13 @@ class HipGraph:
     def replay(self):
         self._ck(self.hip.hipGraphLaunch(self.exe, self.C.c_void_p(self.torch.cuda.current_stream().cuda_stream)), "hipGraphLaunch")
 
+    def __del__(self):
+        try:
+            if self.exe:
+                self.hip.hipGraphExecDestroy(self.exe)
+        except Exception:
+            pass
+
 
 class Runner:
     """One way of advancing `env` by env steps, captured into hipGraphs so that the timed region contains nothing but replays."""
