@@ -229,6 +229,9 @@ static int build_fast_tables(FastTab<S> *T, int variant = 0, int heur = 0)
             if (heur == 1) ev = (double)((tp + 1) - (tn + 1));
             if (heur == 3) ev = (double)(-(np_ + nn));
             if (variant == 1) { volatile double sixth = ev / 6.0, acc = 0.0; for (int d = 0; d < 6; d++) acc = acc + sixth; ev = acc; }
+            // level S-1 is the far corner alone: TOP_LEFT standing there has won, evaluate() = +10 whatever else is on the board
+            // (envs/minimax_ewn.py:41-44; no search reads these rows for anything else -- a root or a leaf that wins)
+            if (tp == S - 1) ev = 10.0;
             e[(size_t)(tp * 8 + np_) * IXN + (tn * 8 + nn)] = ev; used_e[(size_t)(tp * 8 + np_) * IXN + (tn * 8 + nn)] = 1;
             all.push_back(ev);
         }
@@ -250,7 +253,10 @@ static int build_fast_tables(FastTab<S> *T, int variant = 0, int heur = 0)
         for (int iy = 0; iy < IXN; iy++) {
             const bool used = used_e[(size_t)ix * IXN + iy] != 0;
             // a slot no position maps to (count 0 = the side has lost its last cube, envs/minimax_ewn.py:45-47) answers -10
-            T->rank[ix * IXN + iy] = (uint16_t)(8 * (used ? (uint16_t)(1 + (std::lower_bound(all.begin(), all.end(), e[(size_t)ix * IXN + iy]) - all.begin())) : m10));
+            // ... and column 0 of the other rows (BOTTOM_RIGHT has no cube left: TOP_LEFT has won, :41-44) answers +10: the leaves of
+            // the max_depth 5 / 6 search (ewn_search_d5.hpp) that take the last cube land there
+            const uint16_t unused_rank = (heur != 2 && iy == 0 && ix != 0) ? (uint16_t)T->nv : m10;
+            T->rank[ix * IXN + iy] = (uint16_t)(8 * (used ? (uint16_t)(1 + (std::lower_bound(all.begin(), all.end(), e[(size_t)ix * IXN + iy]) - all.begin())) : unused_rank));
         }
     T->rank[0] = (uint16_t)FAST_NONE8; T->rank[1] = (uint16_t)(8 * m10); // unused (level 0, count 0) slots that d3_search's leaf index is steered to: "no such reply", -10
     return 0;

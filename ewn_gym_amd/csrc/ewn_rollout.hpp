@@ -67,7 +67,7 @@ EWN_DEV RState<S> rs_flip(const FastTab<S> *Tb, const RState<S> &s)
 // AGENT 0: RandomAgent (the hash-driven uniform legal pick of ewn_step_out.random_action); 1: ExpectiMinimaxAgent of
 // max_depth 1-4 ('hybrid'); 2: of max_depth 5-6.  OPP as in k_step_d3: 0 minimax max_depth 1-4, 1 RandomAgent, 2 minimax 5-6.
 template <int S, int T, int OPP, int RNGK, int AGENT>
-__global__ __launch_bounds__(D3_BS) void k_rollout_d3(RollCfg c, RollBuf B)
+__global__ __launch_bounds__(D3_BS, ((OPP == 2 || AGENT == 2) ? 2 : 1)) void k_rollout_d3(RollCfg c, RollBuf B) // the max_depth 5 / 6 search: hold it to 256 registers (two waves per SIMD)
 {
     constexpr int CELLS = S * S, GPB = D3_BS / T; // games per block
     constexpr int TS = T > 2 ? 2 : T;             // lanes per game the depth-5 search can use
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(D3_BS) void k_rollout_d3(RollCfg c, RollBuf B)
             // ExpectiMinimaxAgent.predict(canonical observation): the agent's own position IS canonical for it once flipped
             const RState<S> f = rs_flip<S>(Ta, s);
             if constexpr (AGENT == 1) d3_search<S, T>(Ta, f, dice, sub, c.agent_depth, aflag, adir);
-            else d5_search<S, TS>(Ta, f, dice, T > 2 ? (sub & 1) : sub, aflag, adir);
+            else d5_dispatch<S, TS>(Ta, f, dice, T > 2 ? (sub & 1) : sub, aflag, adir);
         }
         if (active) { // a frozen lane's stream stays where its last step left it
             if constexpr (RNGK == 0) r.prefetch();
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(D3_BS) void k_rollout_d3(RollCfg c, RollBuf B)
         // the opponent's search: run by every lane (lanes without a pending reply compute on a harmless state)
         int oflag = 0, odir = 0;
         if constexpr (OPP == 0) d3_search<S, T>(Tb, s, dice, sub, c.depth, oflag, odir);
-        if constexpr (OPP == 2) d5_search<S, TS>(Tb, s, dice, T > 2 ? (sub & 1) : sub, oflag, odir);
+        if constexpr (OPP == 2) d5_dispatch<S, TS>(Tb, s, dice, T > 2 ? (sub & 1) : sub, oflag, odir);
         RSTAMP(2); // search
         if (reply) {
             // opponent half, envs/ewn.py:464-486

@@ -432,6 +432,16 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
     return best;
 }
 
+#include "ewn_search_d5.hpp"
+
+// max_depth 5 / 6 on the image the search was built for: the closed form for the (level, count) images, the loops for 'two_min_dist'
+template <int S, int T, bool H2 = false>
+__device__ __forceinline__ double d5_dispatch(const FastTab<S> *Tb, const RState<S> &c, int dice, int sub, int &bflag, int &bdir)
+{
+    if constexpr (H2) return d5_search<S, T, true>(Tb, c, dice, sub, bflag, bdir);
+    else return d5c_search<S, T>(Tb, c, dice, sub, bflag, bdir);
+}
+
 // The same search from a row-major canonical GState (stateless predict kernel, generic step kernel's fast path)
 template <int S, bool H2 = false>
 __device__ __forceinline__ double fast_d3(const FastTab<S> *Tb, const GState<1> &c, int dice, int depth, int &bflag, int &bdir)
@@ -448,7 +458,7 @@ __device__ __forceinline__ double fast_d3(const FastTab<S> *Tb, const GState<1> 
         s.posP |= (u64)(ap ? rp : PK_OFF) << (8 * k);
         s.posN |= (u64)(an ? rn : PK_OFF) << (8 * k);
     }
-    if (depth >= 5) return d5_search<S, 1, H2>(Tb, s, dice, 0, bflag, bdir);
+    if (depth >= 5) return d5_dispatch<S, 1, H2>(Tb, s, dice, 0, bflag, bdir);
     return d3_search<S, 1, H2>(Tb, s, dice, 0, depth, bflag, bdir);
 }
 
@@ -620,7 +630,7 @@ static __global__ void k_mtq_flip(u32 *ctrl) { if (threadIdx.x == 0 && blockIdx.
 // OPP 0: ExpectiMinimaxAgent(max_depth=3, 'hybrid') reply;  OPP 1: RandomAgent reply (classical_policies/random_policy.py:11-15)
 // RNGK: the dice RNG kind as a compile-time constant, so each instantiation carries only its own generator's registers
 template <int S, int T, int OPP, int RNGK>
-__global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
+__global__ __launch_bounds__(D3_BS, (OPP == 2 ? 2 : 1)) void k_step_d3(D3Cfg c, D3Buf B) // max_depth 5 / 6: held to 256 registers (two waves per SIMD)
 {
     constexpr int CELLS = S * S, GPB = D3_BS / T; // games per block
     // Philox instances whose block fits keep their LDS in a STATIC array: a compile-time address folds into the offset field of
@@ -742,7 +752,7 @@ __global__ __launch_bounds__(D3_BS) void k_step_d3(D3Cfg c, D3Buf B)
     // so the DPP exchanges inside always see their partners
     int oflag = 0, odir = 0;
     if constexpr (OPP == 0) d3_search<S, T>(Tb, s, dice, sub, c.depth, oflag, odir);
-    if constexpr (OPP == 2) d5_search<S, (T > 2 ? 2 : T)>(Tb, s, dice, sub, oflag, odir); // max_depth 5 / 6: its own instances (T = 1, 2), so its registers do not weigh on the others
+    if constexpr (OPP == 2) d5_dispatch<S, (T > 2 ? 2 : T)>(Tb, s, dice, sub, oflag, odir); // max_depth 5 / 6: its own instances (T = 1, 2), so its registers do not weigh on the others
     if (reply) {
         // opponent half, envs/ewn.py:464-486
         const u32 e = pk_sel<S>(Tb, s.posP, dice);
