@@ -260,3 +260,168 @@ __global__ __launch_bounds__(D3_BS, ((OPP == 2 || AGENT == 2) ? 2 : 1)) void k_r
     __syncthreads();
     block_copy_out(B.board + (size_t)g0 * CELLS, lds, ng * CELLS);
 }
+
+// ---------------------------------------------------------------- slot-task rollout (RandomAgent agent, minimax opponent)
+//
+// In k_rollout_d3 every game of a wave walks all six root slots of the opponent's search each step, although the dice selects ONE
+// cube (three roots) in ~85 % of the positions (measured on the bench's rollouts: 80 % of the decisions have exactly three legal
+// moves, 11 % six): a wave always holds some game with a second cube, so the second half of the root loop is always executed and
+// mostly wasted.  Here a loop iteration searches the three roots of ONE cube per game (d3_search / d5c_search in PERLANE mode);
+// a game with a second cube takes one more iteration for the same env step (best / action carried over), the others go on to
+// their next env step.  The games of a wave therefore drift apart by a few steps; every game still plays exactly K steps per
+// launch and writes row k of the trajectory when it finishes its step k -- results are identical to k_rollout_d3's, bit for bit
+// (tests/test_gpu_rollout.py).  A wave leaves the loop when its last game is done: ~K (1 + p) + 2 sqrt(K p (1 - p)) iterations
+// for p = the share of two-cube decisions, against K iterations of twice the search length.
+template <int S, int T, int OPP, int RNGK>
+__global__ __launch_bounds__(D3_BS, (OPP == 2 ? 2 : 1)) void k_rollout_slots(RollCfg c, RollBuf B)
+{
+    static_assert(OPP == 0 || OPP == 2, "minimax opponents");
+    constexpr int CELLS = S * S, GPB = D3_BS / T;   // games per block
+    constexpr int TS = T > 2 ? 2 : T;               // lanes per game the depth-5 search can use
+    constexpr int STR = (CELLS + 15) & ~15;         // LDS bytes per game: a 16-byte aligned staging slot for the board
+    __shared__ __attribute__((aligned(16))) int8_t lds_st[GPB * STR + FAST_TAB_BYTES(S) + GPB * 16];
+    int8_t *lds = lds_st;
+    int8_t *tb = lds + GPB * STR;
+    tables_to_lds<FAST_TAB_BYTES(S)>(tb, (const int8_t *)B.tables); // LDS-DMA, waited for at the barrier
+    const FastTab<S> *Tb = (const FastTab<S> *)tb;
+    uint8_t *garr = (uint8_t *)(tb + FAST_TAB_BYTES(S));
+
+    const int g0 = (int)blockIdx.x * GPB, ng = min(GPB, c.N - g0);
+    const int gl = threadIdx.x / T, sub = threadIdx.x % T, game = g0 + gl;
+    const bool live = game < c.N, writer = live && sub == 0;
+
+    uint4 hdr = make_uint4(0u, 0u, 0u, 0u);
+    int dice = 1;
+    bool frozen = true;
+    if (live) {
+        hdr = *rng_hdr_ptr(B.rng, game);
+        dice = B.dice[game];
+        frozen = B.done[game] != 0;
+    }
+    const bool frozen0 = frozen;
+    // boards come in at their packed stride (the state tensor's layout) and are decoded from there
+    block_copy_in(lds, B.board + (size_t)g0 * CELLS, ng * CELLS);
+    LaneRng r; r.load(RNGK, hdr, rng_win_ptr(B.rng, c.N, c.W, live ? game : 0, RNGF_CUR(hdr.w)), c.W, c.key);
+    r.begin_kernel();
+    lds_dma_wait();
+    __syncthreads();
+    RState<S> s;
+    d3_decode<S, T>(live ? lds + gl * CELLS : lds, sub, garr + gl * 16, s);
+    __syncthreads();                                // every game is in registers: the board area becomes the staging slots
+    int8_t *slot_b = lds + gl * STR;
+    double ret_acc = 0.0;
+    int n_steps = 0, n_eps = 0, n_wins = 0;
+
+    int kdone = 0, phase = 0;                       // env steps finished; 0 = next iteration starts a step, 1 = it searches the second cube
+    double reward = 0.0, best = 0.0;
+    int term = 0, trunc = 0, info = EWN_INFO_NONE, aflag = 0, adir = 0, oflag = 0, odir = 0;
+    bool reply = false;
+    #pragma unroll 1
+    while (true) {
+        const bool pending = live && kdone < c.K;
+        if (__builtin_amdgcn_ballot_w64(pending) == 0) break; // this wave's games have all played K steps
+        const bool start = pending && phase == 0;
+        const bool active = start && !frozen;
+        if (start) {
+            reward = 0.0; term = frozen ? 1 : 0; trunc = 0; info = EWN_INFO_NONE; reply = false; aflag = 0; adir = 0;
+            // RandomAgent.predict for the current observation (the agent is the canonical BOTTOM_RIGHT side): the same draw
+            // ewn_step_out.random_action makes at the end of the previous step
+            const u32 e = pk_sel<S>(Tb, s.posN, dice), pp = pk_pair(s.posN, e);
+            const u32 okm = (u32)Tb->lgn[pp & 0xFFu] | ((u32)Tb->lgn[pp >> 8] << 3);
+            const int n = __popc(okm);
+            if (n > 0) {
+                const u32 w = agent_hash(r.seed_mix(), r.draws(), (u32)(c.lane_offset + game), c.key);
+                const int sl = Tb->nth[okm * 8u + __umulhi(w, (u32)n)];
+                aflag = sl < 3 ? (int)(e >> 15) : 0;
+                adir = sl < 3 ? sl : sl - 3;
+            }
+            if (active) { // a frozen lane's stream stays where its last step left it
+                if constexpr (RNGK == 0) r.prefetch();
+                r.begin_step();
+                if constexpr (RNGK == 1) r.ps.prime();
+                // agent half, envs/ewn.py:438-458
+                const int k = pk_cube(e, aflag == 1);
+                const int q = Tb->nbn[adir][pk_get(s.posN, k)]; // no cube at all: byte 6 -> 255
+                if (q == 255) { reward = -c.reward; term = 1; trunc = 1; info = EWN_INFO_INVALID_PLAYER; }
+                else {
+                    rs_move<S, false>(s, k, q);
+                    if (q == Tb->ri_origin || s.P == 0) { reward = c.reward; term = 1; info = EWN_INFO_WON; }
+                    else { dice = r.randint(1, 7); reply = true; }
+                }
+            }
+        }
+        // one cube's three roots of the opponent's search, run by every lane (lanes without a pending reply compute on a harmless
+        // state, so the DPP exchanges inside always see their partners)
+        bool second = false;
+        if constexpr (OPP == 0) best = d3_search<S, T, false, true>(Tb, s, dice, sub, c.depth, oflag, odir, phase, best, &second);
+        else best = d5c_search<S, TS, true>(Tb, s, dice, T > 2 ? (sub & 1) : sub, oflag, odir, phase, best, &second);
+        if (pending && phase == 0 && reply && second) phase = 1; // the same env step goes on with the second cube
+        else if (pending) {
+            phase = 0;
+            if (reply) {
+                // opponent half, envs/ewn.py:464-486
+                const u32 e = pk_sel<S>(Tb, s.posP, dice);
+                const int k = pk_cube(e, oflag == 1);
+                const int q = Tb->nbp[odir][pk_get(s.posP, k)];
+                rs_move<S, true>(s, k, q);
+                if (q == CELLS - 1 || s.N == 0) { reward = -c.reward; term = 1; info = EWN_INFO_LOST; }
+                else dice = r.randint(1, 7);
+            }
+            if (!frozen) {
+                ret_acc += reward; n_steps++; n_eps += term; n_wins += info == EWN_INFO_WON ? 1 : 0;
+                if (term) {
+                    if (c.autoreset) { // reset(seed = next_seed) + setup_game (envs/ewn.py:488-494, 94-108); Philox kind only (host check)
+                        r.next_episode(B.rng, c.N, game, c.seed_stride, c.key, nullptr);
+                        d3_init_state<S>(Tb, s);
+                        dice = r.first_dice(6);
+                    } else frozen = true;
+                }
+            }
+            // ---- row kdone of the trajectory
+            const size_t o = (size_t)kdone * c.N + game;
+            if (sub == 0) {
+                if (B.t_action) ((uint16_t *)B.t_action)[o] = (uint16_t)((uint8_t)aflag | ((uint16_t)(uint8_t)adir << 8));
+                if (B.t_dice) B.t_dice[o] = (int8_t)dice;
+                if (B.t_reward) B.t_reward[o] = reward;
+                if (B.t_term) B.t_term[o] = (uint8_t)term;
+                if (B.t_trunc) B.t_trunc[o] = (uint8_t)trunc;
+                if (B.t_info) B.t_info[o] = (uint8_t)info;
+            }
+            if (B.t_board) {
+                // the game's board through its own 16-byte aligned LDS slot: zero it, drop the cube bytes in, copy it out (LDS
+                // operations of one wave execute in program order; the T lanes of a game are in one wave)
+                #pragma unroll
+                for (int i = sub; i < STR / 16; i += T) ((uint4 *)slot_b)[i] = make_uint4(0u, 0u, 0u, 0u);
+                d3_encode_cubes<S, T>(Tb, s, sub, slot_b);
+                // copy out: each of the T lanes a contiguous run of whole dwords, the last lane the odd tail.  The row sits at a
+                // byte offset of o * CELLS: an UNALIGNED destination, which global memory accepts (the compiler knows: a 4-byte
+                // memcpy to a char pointer becomes one dword store on this target); a quarter of the requests of a byte copy
+                constexpr int CH = ((CELLS / T + 3) & ~3) < CELLS ? ((CELLS / T + 3) & ~3) : (CELLS & ~3); // bytes per lane, whole dwords
+                int8_t *dst = B.t_board + o * CELLS;
+                #pragma unroll
+                for (int i = 0; i < CH; i += 4) {
+                    const int at = sub * CH + i;
+                    if (at + 4 <= CELLS) { const u32 w = *(const u32 *)(slot_b + at); __builtin_memcpy(dst + at, &w, 4); }
+                }
+                if (sub == T - 1) {
+                    #pragma unroll
+                    for (int i = (T * CH < CELLS ? T * CH : (CELLS & ~3)); i < CELLS; i++) dst[i] = slot_b[i];
+                }
+            }
+            kdone++;
+        }
+    }
+    // ---- the state goes back to HBM once, through the packed board area
+    __syncthreads();
+    if (live) d3_encode<S, T>(Tb, s, sub, lds + gl * CELLS);
+    if (writer) {
+        if (!frozen0) { *rng_hdr_ptr(B.rng, game) = r.header(); B.dice[game] = (int8_t)dice; }
+        B.done[game] = frozen ? 1 : 0;
+        if (B.ret_sum) B.ret_sum[game] += ret_acc;
+        if (B.n_steps) B.n_steps[game] += n_steps;
+        if (B.n_episodes) B.n_episodes[game] += n_eps;
+        if (B.n_wins) B.n_wins[game] += n_wins;
+    }
+    __syncthreads();
+    block_copy_out(B.board + (size_t)g0 * CELLS, lds, ng * CELLS);
+}

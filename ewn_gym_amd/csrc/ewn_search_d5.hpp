@@ -96,8 +96,10 @@ EWN_DEV u32 d5c_alive_after(u64 posP, u32 q)
     return pk_alive(pk_capture(posP, qb));
 }
 
-template <int S, int T>
-__device__ __forceinline__ double d5c_search(const FastTab<S> *Tb, const RState<S> &c, int dice, int sub, int &bflag, int &bdir)
+// PERLANE: one call = the three roots of one root cube (slotL), best / bflag / bdir carried in and out -- see d3_search.
+template <int S, int T, bool PERLANE = false>
+__device__ __forceinline__ double d5c_search(const FastTab<S> *Tb, const RState<S> &c, int dice, int sub, int &bflag, int &bdir,
+                                             int slotL = 0, double best_in = 0.0, bool *have_second = nullptr)
 {
     static_assert(T == 1 || T == 2, "one or two lanes per game");
     typedef typename MaskOf<S>::type M;
@@ -105,12 +107,15 @@ __device__ __forceinline__ double d5c_search(const FastTab<S> *Tb, const RState<
     const M one = 1;
     const double inf = __builtin_inf();
     double best = -inf;
-    bflag = 0; bdir = 0;
     const u32 e0 = pk_sel<S>(Tb, c.posP, dice), pp0 = pk_pair(c.posP, e0);
+    if constexpr (PERLANE) {
+        *have_second = !((pp0 >> 8) & PK_OFF);
+        if (slotL == 0) { bflag = 0; bdir = 0; } else best = best_in;
+    } else { bflag = 0; bdir = 0; }
 
     #pragma unroll 1
-    for (int r = 0; r < 6; r++) {
-        const int slot = r >= 3 ? 1 : 0, dir = r - 3 * slot;
+    for (int r = 0; r < (PERLANE ? 3 : 6); r++) {
+        const int slot = PERLANE ? slotL : (r >= 3 ? 1 : 0), dir = PERLANE ? r : r - 3 * slot;
         const int cube = (int)((slot ? e0 >> 8 : e0) & 7u), rb = (int)((slot ? pp0 >> 8 : pp0) & 0xFFu);
         const int dest = Tb->nbp[dir][rb];
         const bool valid = dest != 255;                // no such cube (byte 6) or off the board

@@ -256,8 +256,12 @@ template <int T> EWN_DEV void publish(u32 mine, int i, u32 (&out)[6])
 // v_and_or for the root-invariant exceptions; ranks travel as byte offsets (8 x rank) so that value reads need no shift either;
 // a cube's result is ONE 16-bit key (the cut-off value if its replies cut, else 0x8000 | minimum) so that the pair selection per
 // dice is a compare, a min and a select; the lanes exchange keys and chosen ranks, never doubles.
-template <int S, int T, bool H2 = false>
-__device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S> &c, int dice, int sub, int depth, int &bflag, int &bdir)
+// PERLANE (the slot-task rollout kernel, ewn_rollout.hpp): one call searches the three roots of ONE root cube -- slotL = 0: the
+// first cube of the legal list, 1: the second -- and carries best / bflag / bdir in and out, so that a game whose dice selects a
+// single cube (most do) is finished after one call; returns through `have_second` whether the list has a second cube.
+template <int S, int T, bool H2 = false, bool PERLANE = false>
+__device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S> &c, int dice, int sub, int depth, int &bflag, int &bdir,
+                                            int slotL = 0, double best_in = 0.0, bool *have_second = nullptr)
 {
     typedef typename MaskOf<S>::type M;
     constexpr int KPT = 6 / T + (6 % T ? 1 : 0); // replier cubes / dice values per lane: k = sub + T*i
@@ -271,7 +275,10 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
     const int rp0 = rb0 & 63, rp1 = rb1 & 63;
 
     double best = -__builtin_inf(); // alpha = max(alpha, best_val): the running best (root beta stays +inf)
-    bflag = 0; bdir = 0;
+    if constexpr (PERLANE) {
+        *have_second = have1;
+        if (slotL == 0) { bflag = 0; bdir = 0; } else best = best_in;
+    } else { bflag = 0; bdir = 0; }
 
     if (depth < 3) {
         // max_depth 1 and 2 bottom out before the replier moves (classical_policies/minimax.py:19-73: every node, chance nodes
@@ -295,6 +302,7 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
             v = term ? 10.0 : (depth == 1 ? e1 : v);
             if (valid && v > best) { best = v; bflag = slot == 0 ? flag0 : 0; bdir = dir; }
         }
+        if constexpr (PERLANE) *have_second = false; // both cubes were searched in this one call
         return best;
     }
 
@@ -324,13 +332,17 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
         }
     }
 
+    // the six root destinations, read before the loop: inside it the read's whole latency stood in front of every root
+    const u32 dq0 = (u32)Tb->nbp[0][rp0] | ((u32)Tb->nbp[1][rp0] << 8) | ((u32)Tb->nbp[2][rp0] << 16);
+    const u32 dq1 = (u32)Tb->nbp[0][rp1] | ((u32)Tb->nbp[1][rp1] << 8) | ((u32)Tb->nbp[2][rp1] << 16);
+
     // a real loop, not unrolled: the body is ~300 instructions and six copies of it (plus the rest of the
     // kernel) do not fit the instruction cache shared by two CUs
     #pragma unroll 1
-    for (int r = 0; r < 6; r++) {
-        const int slot = r >= 3 ? 1 : 0, dir = r - 3 * slot;
+    for (int r = 0; r < (PERLANE ? 3 : 6); r++) {
+        const int slot = PERLANE ? slotL : (r >= 3 ? 1 : 0), dir = PERLANE ? r : r - 3 * slot;
         const int rp = slot == 0 ? rp0 : rp1;
-        const int dest = Tb->nbp[dir][rp];
+        const int dest = (int)(((slot == 0 ? dq0 : dq1) >> (8 * dir)) & 0xFFu);
         const bool valid = (slot == 0 ? have0 : have1) && dest != 255;
         const M bd = valid ? (one << dest) : (M)0;
         const M P1 = (c.P & ~(one << rp)) | bd; // own capture: the bit is already set, the count drops by itself

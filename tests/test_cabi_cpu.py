@@ -122,9 +122,9 @@ def test_mt_refill_queue_fits_every_lanes_per_game_choice():
 
 
 def test_default_kernel_selection_is_not_changed_by_the_environment():
-    """EWN_D3_T / EWN_ROLLOUT_T are tuning knobs read once by the library; with neither set (as in every test and bench run) the
+    """EWN_D3_T / EWN_ROLLOUT_T / EWN_ROLLOUT_SLOTS (0 = the lock-step rollout kernel at every size) are tuning knobs read once by the library; with neither set (as in every test and bench run) the
     lanes-per-game choice is a function of the lane count alone, at the measured thresholds."""
-    assert "EWN_D3_T" not in os.environ and "EWN_ROLLOUT_T" not in os.environ
+    assert "EWN_D3_T" not in os.environ and "EWN_ROLLOUT_T" not in os.environ and "EWN_ROLLOUT_SLOTS" not in os.environ
     lib = _lib.load()
     lanes = lambda entry, **kw: lib.ewn_lanes_per_game(C.byref(cfg(rng_kind=1, autoreset=1, **kw)), entry)  # noqa: E731
     for entry in (0, 1):

@@ -102,6 +102,31 @@ def test_rollout_other_board_sizes(ea, S):
     _rollout_vs_oracle(ea, 40000, 20000, 20128, 5, 2, board_size=S, opponent_policy="random", rng="philox", philox_key=S + 1, board_column=False)
 
 
+SLOT_N = 66000   # two lanes per game x 66 000 games >= 131 072 lanes: the launcher picks k_rollout_slots (one root cube per loop iteration)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(max_depth=1), dict(max_depth=2), dict(max_depth=4), dict(max_depth=3, heuristic="min_dist"), dict(max_depth=4, heuristic="attk"),
+    dict(max_depth=5), dict(max_depth=6, heuristic="attk"), dict(max_depth=3, board_size=6), dict(max_depth=3, board_size=7),
+    dict(max_depth=4, board_size=8), dict(max_depth=5, board_size=7),
+], ids=lambda kw: "-".join("%s=%s" % kv for kv in sorted(kw.items())))
+def test_rollout_slot_task_kernel_every_search(ea, kw):
+    """The slot-task rollout kernel (games of a wave drift apart by a few env steps inside a launch) against the oracle: every
+    table-driven depth class, heuristic image and board size, state carried over three launches, trajectory rows included."""
+    lo = 40000
+    _rollout_vs_oracle(ea, SLOT_N, lo, lo + (96 if kw["max_depth"] >= 5 else 256), 7, 3, opponent_policy="minimax", rng="philox",
+                       philox_key=1000 + kw["max_depth"], **kw)
+
+
+def test_rollout_slot_task_kernel_frozen_lanes_and_numpy_dice(ea):
+    """... without auto-reset (lanes freeze as their episode ends, and go on writing their rows) on the MT19937-compat dice, with
+    and without the board column; one lane per game at 140 000 lanes."""
+    _rollout_vs_oracle(ea, SLOT_N, 100, 400, 9, 4, autoreset=False, opponent_policy="minimax", max_depth=3, rng="mt19937")
+    _rollout_vs_oracle(ea, SLOT_N, 65000, 65300, 9, 2, autoreset=False, opponent_policy="minimax", max_depth=5, rng="mt19937", board_column=False)
+    _rollout_vs_oracle(ea, 140000, 139700, 140000, 11, 3, autoreset=False, opponent_policy="minimax", max_depth=3, rng="mt19937")
+    _rollout_vs_oracle(ea, 140000, 0, 200, 6, 2, opponent_policy="minimax", max_depth=5, rng="philox", philox_key=5, board_column=False)
+
+
 def test_rollout_random_opponent_and_mt19937_without_autoreset(ea):
     _rollout_vs_oracle(ea, 3000, 1000, 1600, 10, 3, opponent_policy="random", rng="philox", philox_key=3)
     # numpy-compatible dice, one episode per lane (the evaluation scripts' shape): lanes freeze as they finish

@@ -1,5 +1,5 @@
 """One-off soak: lock-step HIP vs CPU oracle on many lanes and steps (all six outputs bit-exact), beyond what tests/ runs.
-usage (GPU box): python tools/soak_parity.py [mcts | predict | r02]"""
+usage (GPU box): python tools/soak_parity.py [mcts | predict | r02 | d5]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -60,6 +60,33 @@ def positions(S, L, n, seed, max_steps=24):
         out[when == t] = b[when == t]
     return out, gen.integers(1, 7, n).astype(np.int8)
 
+def roll(N, K, launches, lo, hi, agent="random", agent_max_depth=3, autoreset=True, **kw):
+    okw = dict(kw); opp = okw.pop("opponent_policy")
+    env = ea.VecEWN(N, opponent_policy=opp, autoreset=autoreset, seed_stride=N, **okw)
+    seeds = (np.arange(N, dtype=np.uint64) * 3 + 99).astype(np.uint32)
+    env.reset(seeds=seeds)
+    orc = po.OracleVecEnv(hi - lo, opponent=opp, autoreset=autoreset, seed_stride=N, lane_offset=lo, **okw)
+    ob, od = orc.reset(seeds=seeds[lo:hi])
+    traj = env.alloc_rollout(K)
+    frozen = np.zeros(hi - lo, bool)
+    t0 = time.time(); nterm = 0
+    for launch in range(launches):
+        env.rollout(K, agent=agent, agent_max_depth=agent_max_depth, traj=traj)
+        tj = {k: v[:, lo:hi].cpu().numpy() for k, v in traj.items()}
+        for k in range(K):
+            acts = orc.random_actions() if agent == "random" else po.predict_minimax(ob, od, agent_max_depth, "hybrid")[0]
+            live = ~frozen
+            assert np.array_equal(tj["action"][k][live], acts[live]), (kw, launch, k)
+            ob, od, r, te, tr, info = orc.step(np.where(live[:, None], acts, 0).astype(np.int8))
+            for name, o in (("board", ob), ("dice", od), ("terminated", te), ("truncated", tr), ("info", info)):
+                assert np.array_equal(tj[name][k], o), (kw, launch, k, name)
+            assert np.array_equal(bits(tj["reward"][k]), bits(r)), (kw, launch, k)
+            nterm += int((live & (te != 0)).sum())
+            if not autoreset:
+                frozen |= te != 0
+    print("ok rollout N=%d K=%d launches=%d slice=%d episodes=%d agent=%s %r (%.1f s)" % (N, K, launches, hi - lo, nterm, agent, kw, time.time() - t0), flush=True)
+
+
 if len(sys.argv) > 1 and sys.argv[1] == "mcts":
     for S, n, total in ((5, 300, 1000), (7, 120, 400), (8, 60, 333), (5, 2000, 13)):
         b, d = positions(S, 3, n, 77 + S)
@@ -85,6 +112,31 @@ if len(sys.argv) > 1 and sys.argv[1] == "predict":
             print("ok predict S=%d depth=%d positions=%d (%.1f s)" % (S, depth, n, time.time() - t0), flush=True)
     print("predict soak passed")
 
+if len(sys.argv) > 1 and sys.argv[1] == "d5":
+    # the closed-form max_depth 5 / 6 search (ewn_search_d5.hpp): stateless predicts on every board size and (level, count) image,
+    # then the step and rollout kernels at one and at two lanes per game
+    for S in (5, 6, 7, 8):
+        for heur in ("hybrid", "min_dist", "attk"):
+            for depth, n in ((5, 40000 if heur == "hybrid" else 8000), (6, 6000 if heur == "hybrid" else 1500)):
+                b, d = positions(S, 3, n, 9000 + 10 * S + depth, max_steps=14 if S == 5 else 26)
+                t0 = time.time()
+                acts, vals = ea.predict_minimax(b, d, depth, heur)
+                oa, ov, _ = po.predict_minimax(b, d, depth, heur)
+                assert np.array_equal(acts.cpu().numpy(), oa) and np.array_equal(bits(vals.cpu().numpy()), bits(ov)), (S, heur, depth)
+                print("ok predict S=%d %s depth=%d positions=%d (%.1f s)" % (S, heur, depth, n, time.time() - t0), flush=True)
+    run(65536, 40, 30000, 31500, opponent_policy="minimax", max_depth=5, rng="philox", philox_key=41)          # two lanes per game
+    run(140000, 30, 139000, 140000, opponent_policy="minimax", max_depth=5, rng="philox", philox_key=42)       # one lane per game
+    run(40000, 30, 0, 800, opponent_policy="minimax", max_depth=6, rng="mt19937")
+    run(40000, 30, 39000, 40000, opponent_policy="minimax", max_depth=5, heuristic="min_dist", rng="philox", philox_key=43, board_size=7)
+    run(33000, 30, 0, 800, opponent_policy="minimax", max_depth=6, heuristic="attk", rng="philox", philox_key=44, board_size=8)
+    run(33000, 30, 0, 800, opponent_policy="minimax", max_depth=5, rng="philox", philox_key=45, board_size=6)
+
+    roll(65536, 12, 2, 20000, 21000, opponent_policy="minimax", max_depth=5, rng="philox", philox_key=46)
+    roll(140000, 8, 2, 0, 600, opponent_policy="minimax", max_depth=5, rng="philox", philox_key=47)
+    roll(2048, 10, 4, 0, 1024, agent="minimax", agent_max_depth=5, autoreset=False, opponent_policy="minimax", max_depth=5, rng="mt19937")
+    roll(2048, 10, 4, 0, 512, agent="minimax", agent_max_depth=6, autoreset=False, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=48, board_size=7)
+    print("d5 soak passed")
+
 if len(sys.argv) > 1 and sys.argv[1] == "r02":
     # round 2 paths: shaped env and integer heuristics on the table-driven kernel, K-step rollouts (ewn_step_k)
     run(40000, 60, 1000, 3000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=21, shaped=True, reward=10.0,
@@ -94,32 +146,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "r02":
     run(20000, 50, 4000, 6000, opponent_policy="minimax", max_depth=4, heuristic="attk", rng="mt19937")
     run(6000, 30, 0, 1500, opponent_policy="minimax", max_depth=5, heuristic="attk", rng="philox", philox_key=23)
     run(10000, 40, 0, 2000, opponent_policy="minimax", max_depth=3, heuristic="min_dist", rng="philox", philox_key=24, board_size=7)
-
-    def roll(N, K, launches, lo, hi, agent="random", agent_max_depth=3, autoreset=True, **kw):
-        okw = dict(kw); opp = okw.pop("opponent_policy")
-        env = ea.VecEWN(N, opponent_policy=opp, autoreset=autoreset, seed_stride=N, **okw)
-        seeds = (np.arange(N, dtype=np.uint64) * 3 + 99).astype(np.uint32)
-        env.reset(seeds=seeds)
-        orc = po.OracleVecEnv(hi - lo, opponent=opp, autoreset=autoreset, seed_stride=N, lane_offset=lo, **okw)
-        ob, od = orc.reset(seeds=seeds[lo:hi])
-        traj = env.alloc_rollout(K)
-        frozen = np.zeros(hi - lo, bool)
-        t0 = time.time(); nterm = 0
-        for launch in range(launches):
-            env.rollout(K, agent=agent, agent_max_depth=agent_max_depth, traj=traj)
-            tj = {k: v[:, lo:hi].cpu().numpy() for k, v in traj.items()}
-            for k in range(K):
-                acts = orc.random_actions() if agent == "random" else po.predict_minimax(ob, od, agent_max_depth, "hybrid")[0]
-                live = ~frozen
-                assert np.array_equal(tj["action"][k][live], acts[live]), (kw, launch, k)
-                ob, od, r, te, tr, info = orc.step(np.where(live[:, None], acts, 0).astype(np.int8))
-                for name, o in (("board", ob), ("dice", od), ("terminated", te), ("truncated", tr), ("info", info)):
-                    assert np.array_equal(tj[name][k], o), (kw, launch, k, name)
-                assert np.array_equal(bits(tj["reward"][k]), bits(r)), (kw, launch, k)
-                nterm += int((live & (te != 0)).sum())
-                if not autoreset:
-                    frozen |= te != 0
-        print("ok rollout N=%d K=%d launches=%d slice=%d episodes=%d agent=%s %r (%.1f s)" % (N, K, launches, hi - lo, nterm, agent, kw, time.time() - t0), flush=True)
 
     roll(65536, 50, 4, 30000, 32000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=31)
     roll(262144, 25, 2, 200000, 201000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=32)
