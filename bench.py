@@ -414,7 +414,7 @@ def main():
                 traffic = valu = None
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "valu_issue": valu,
-                "kernel": "k_rollout_d3 (K fused env steps per launch)" if mode == "rollout" else "k_step (fused agent move + opponent search + reply + auto-reset)",
+                "kernel": "k_rollout_slots / k_rollout_d3 (K fused env steps per launch; the slot-task kernel from 131 072 lanes x lanes-per-game)" if mode == "rollout" else "k_step (fused agent move + opponent search + reply + auto-reset)",
                 "kernel_ms": kms, "kernel_ms_rocprof": rocprof_ms, "env_steps_per_launch": steps_per_launch, "algorithmic_bytes_per_launch": algo,
                 "note": "integer/fp64-compare search work: VALU-bound, far from the HBM roof by construction (SURVEY 8d); kernel_ms = one HIP "
                         "event pair on the launch stream around the timed region / launches; kernel_ms_rocprof = rocprofv3 --kernel-trace --stats average of the same "

@@ -55,9 +55,9 @@ def main():
     out = {"source_hash": source_hash(), "git_head_when_summarised": head}
     mixp = os.path.join(dst, "isa_mix.json")
     probe = os.path.join(dst, "valu_probe.json")
-    cfgs = (("rollout_k50", "k_rollout_d3", pmc_key("rollout", "minimax", 3, "philox", 5, 65536, 50, True), 50),
-            ("rollout_k20", "k_rollout_d3", pmc_key("rollout", "minimax", 3, "philox", 5, 65536, 20, True), 20),
-            ("rollout_k50_notraj", "k_rollout_d3", pmc_key("rollout", "minimax", 3, "philox", 5, 65536, 50, False), 50),
+    cfgs = (("rollout_k50", "k_rollout", pmc_key("rollout", "minimax", 3, "philox", 5, 65536, 50, True), 50),
+            ("rollout_k20", "k_rollout", pmc_key("rollout", "minimax", 3, "philox", 5, 65536, 20, True), 20),
+            ("rollout_k50_notraj", "k_rollout", pmc_key("rollout", "minimax", 3, "philox", 5, 65536, 50, False), 50),
             ("step", "k_step_d3", pmc_key("step", "minimax", 3, "philox", 5, 65536, 1, True), 1))
     for name, kern, key, K in cfgs:
         d = os.path.join(src, name)
@@ -109,7 +109,7 @@ def main():
         mix = json.load(open(mixp))
         # the peak the dominant (rollout) kernel's instruction mix could issue at, chip-wide
         for kname, kv in mix["kernels"].items():
-            if "k_rollout_d3ILi5ELi2ELi0ELi1ELi0E" in kname and "peak_wave_insts_per_s" in kv:  # the headline instance
+            if "k_rollout_slotsILi5ELi2ELi0ELi1E" in kname and "peak_wave_insts_per_s" in kv:  # the headline instance
                 out["valu_issue_peak_per_s"] = kv["peak_wave_insts_per_s"]["hot_loop"]
                 out["valu_issue_peak_source"] = "tools/isa_mix.py hot loop of %s priced with tools/valu_probe.py (profiles/r02/valu_probe.json)" % kname
     json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
