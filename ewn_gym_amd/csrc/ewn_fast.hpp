@@ -34,6 +34,11 @@
 #define FAST_NONE8 (1023u * 8u)             // "no such reply": val = +inf
 #define FAST_KNONE (0x8000u | FAST_NONE8)   // key (see d3_search) of a cube that is not on the board
 
+template <int S> struct MaskOf { typedef u32 type; };
+template <> struct MaskOf<6> { typedef u64 type; };
+template <> struct MaskOf<7> { typedef u64 type; };
+template <> struct MaskOf<8> { typedef u64 type; };
+
 template <int S>
 struct FastTab {
     static constexpr int CELLS = S * S;
@@ -65,6 +70,13 @@ struct FastTab {
     // ring index -> max(row, col) of the canonical square = the REAL square's distance to the real bottom-right corner, which is
     // what the shaped training env's evaluate() measures for both sides (envs/training_ewn.py:94-96, envs/minimax_ewn.py:67-76)
     uint8_t dtl[64];
+    // the replier's (BOTTOM_RIGHT's) moves for d3_search's per-search setup, [direction][position byte] (bytes 64..127 = no such cube):
+    // the destination's bit in the occupancy mask (0: the move leaves the board), and what steers the leaf's rank address --
+    // keep | fixed << 16 with (address & keep) | fixed: a normal reply keeps the address, a reply that does not exist reads rank[0]
+    // ("no such reply"), a reply onto the origin rank[1] (-10, envs/minimax_ewn.py:45-47).  Two LDS reads where the setup spent
+    // eight VALU instructions per reply; the slot-task rollout kernel runs that setup once per THREE roots.
+    uint32_t rkf[3][128];
+    typename MaskOf<S>::type rsetT[3][128];
 };
 
 // table images per board size: [heuristic image][variant]; heuristic images: 'hybrid', 'min_dist', 'attk' (functions of each side's
@@ -80,10 +92,6 @@ static inline bool fast_heur_lean(int heur) { return heur == 0 || heur == 1 || h
 // LDS / device image size: the struct padded to 4 KiB so the LDS-DMA copy needs no tail handling
 #define FAST_TAB_BYTES(S) ((int)((sizeof(FastTab<S>) + 4095) / 4096 * 4096))
 
-template <int S> struct MaskOf { typedef u32 type; };
-template <> struct MaskOf<6> { typedef u64 type; };
-template <> struct MaskOf<7> { typedef u64 type; };
-template <> struct MaskOf<8> { typedef u64 type; };
 
 EWN_DEV int clz_m(u32 m) { return __clz((int)m); }       // 32 for m == 0
 EWN_DEV int clz_m(u64 m) { return __clzll((long long)m); } // 64 for m == 0
@@ -156,6 +164,13 @@ static int build_fast_tables(FastTab<S> *T, int variant = 0, int heur = 0)
             const int di = d == 0 ? 0 : 1, dj = d == 1 ? 0 : 1;
             if (i + di < S && j + dj < S) T->nbp[d][q] = (uint8_t)ring_of_rm[(i + di) * S + (j + dj)];
             if (i - di >= 0 && j - dj >= 0) T->nbn[d][q] = (uint8_t)ring_of_rm[(i - di) * S + (j - dj)];
+        }
+    for (int d = 0; d < 3; d++)
+        for (int q = 0; q < 128; q++) {
+            const int dn = T->nbn[d][q];
+            const bool ok = dn != 255, home = ok && dn == T->ri_origin;
+            T->rsetT[d][q] = ok ? (typename MaskOf<S>::type)1 << dn : (typename MaskOf<S>::type)0;
+            T->rkf[d][q] = ((ok && !home) ? 0xFFFFu : 0u) | ((home ? 2u : 0u) << 16);
         }
     for (int q = 0; q < 128; q++) {
         T->lgp[q] = T->lgn[q] = 0;

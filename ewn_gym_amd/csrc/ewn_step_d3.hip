@@ -4,6 +4,23 @@
 #include "ewn_lds.hpp"
 #include "ewn_step_d3.hpp"
 
+// one k_step_d3 instance; a dynamic-LDS request above the 64 KB default (the larger boards at one lane per game, the MT19937
+// kind's refill area on top) raises the kernel's limit first, once (gfx950: 160 KB per workgroup)
+template <int SS, int TT, int OO, int RR>
+static int d3_launch_one(dim3 grid, size_t lds, hipStream_t s, const D3Cfg &dc, const D3Buf &db)
+{
+    auto kern = k_step_d3<SS, TT, OO, RR>;
+    if (lds > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return EWN_ELAUNCH;
+            raised = true;
+        }
+    }
+    kern<<<grid, D3_BS, lds, s>>>(dc, db);
+    return EWN_OK;
+}
+
 int ewn_launch_step_d3(const ewn_config *cfg, const Geom &g, const KCfg &k, const ewn_state *st, const void *tables, const int8_t *actions,
                        const ewn_step_out *out, void *scratch, bool lean_random, bool fused_refill, hipStream_t s)
 {
@@ -26,16 +43,17 @@ int ewn_launch_step_d3(const ewn_config *cfg, const Geom &g, const KCfg &k, cons
     if (fused_refill) l3 += 16 + (size_t)2 * gpb * 16;
     const size_t need_refill = fused_refill ? (size_t)(k.W + 1) * 65 * 4 : 0;
 #define D3_LDS(SS) (l3 + FAST_TAB_BYTES(SS) > need_refill ? l3 + FAST_TAB_BYTES(SS) : need_refill)
-#define D3_LAUNCH(SS, TT, OO) do { if (k.rng_kind == 0) k_step_d3<SS, TT, OO, 0><<<grid, D3_BS, D3_LDS(SS), s>>>(dc, db); \
-                                   else k_step_d3<SS, TT, OO, 1><<<grid, D3_BS, d3_lds_static<SS, TT, 1>() ? 0 : D3_LDS(SS), s>>>(dc, db); } while (0)
+#define D3_LAUNCH(SS, TT, OO) do { if (k.rng_kind == 0) lrc = d3_launch_one<SS, TT, OO, 0>(grid, D3_LDS(SS), s, dc, db); \
+                                   else lrc = d3_launch_one<SS, TT, OO, 1>(grid, d3_lds_static<SS, TT, 1>() ? 0 : D3_LDS(SS), s, dc, db); } while (0)
 #define D3_BY_T(SS) do { if (lean_random) D3_LAUNCH(SS, 1, 1); else if (cfg->max_depth > 4) { if (T == 2) D3_LAUNCH(SS, 2, 2); else D3_LAUNCH(SS, 1, 2); } else if (T == 1) D3_LAUNCH(SS, 1, 0); else if (T == 2) D3_LAUNCH(SS, 2, 0); else D3_LAUNCH(SS, 4, 0); } while (0)
+    int lrc = EWN_OK;
     switch (g.S) {
     case 5: D3_BY_T(5); break;
     case 6: D3_BY_T(6); break;
     case 7: D3_BY_T(7); break;
     default: D3_BY_T(8); break;
     }
-    int rc = launch_status();
+    int rc = lrc != EWN_OK ? lrc : launch_status();
     if (rc == EWN_OK && fused_refill) {
         k_mtq_flip<<<1, 64, 0, s>>>((u32 *)scratch);
         rc = launch_status();

@@ -323,12 +323,10 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
         mine_alive |= ((rb & PK_OFF) ? 0u : 1u) << i;
         #pragma unroll
         for (int d = 0; d < 3; d++) {
-            const int dn = Tb->nbn[d][rb];
-            const bool ok = dn != 255;
-            rset[i][d] = ok ? (one << dn) : (M)0;
-            const bool home = ok && dn == Tb->ri_origin;
-            keep[i][d] = (ok && !home) ? ~0u : 0u;
-            fixed[i][d] = home ? 2u : 0u;
+            const u32 kf = Tb->rkf[d][rb];
+            rset[i][d] = Tb->rsetT[d][rb];
+            keep[i][d] = kf & 0xFFFFu;    // rank addresses stay below 2^13
+            fixed[i][d] = kf >> 16;
         }
     }
 
