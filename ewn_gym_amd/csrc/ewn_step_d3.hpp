@@ -222,6 +222,7 @@ __device__ __forceinline__ double d5_search(const FastTab<S> *Tb, const RState<S
 #define D3_PRIO_HI() __builtin_amdgcn_s_setprio(2)
 #define D3_PRIO_LO() __builtin_amdgcn_s_setprio(0)
 #define D3_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define D3_CUT 0x4000u    // key flag of d3_search: the reply loop stops inside this cube's replies (byte-offset ranks stay below 0x2000)
 
 // element `sub + T * i` of a six-element array held identically by the T lanes of a group, for the lane with index `sub`
 template <int T> EWN_DEV u32 own_of(const u32 (&v)[6], int i, int sub)
@@ -401,20 +402,22 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
                 // The cube's key: its cut value if it cuts, else 0x8000 | its minimum.  A cube that is off the board (or was just
                 // captured by the root move) reads garbage leaves above: its key is forced to "no such cube" here.
                 u32 key = 0x8000u | p2[ii];
-                key = v2[ii] <= best ? p2[ii] : key;
-                key = v1[ii] <= best ? p1[ii] : key;
-                key = va[ii] <= best ? a[ii][0] : key;
+                key = v2[ii] <= best ? (p2[ii] | D3_CUT) : key;
+                key = v1[ii] <= best ? (p1[ii] | D3_CUT) : key;
+                key = va[ii] <= best ? (a[ii][0] | D3_CUT) : key;
                 const bool there = ((mine_alive >> i) & 1u) && rnk[i] != dest;
                 key = there ? key : FAST_KNONE;
                 publish<T>(key, i, tr); // after this every lane holds tr[k] for all six cubes (cube k = j + T*i lives in lane j)
             }
         }
         // which cubes a dice value selects (find_near_cube): carry the nearest on-board cube's key along
+        // A key that cuts carries D3_CUT (ranks stay below it, "does not cut" keys above it); the copy that travels as "nearest cube
+        // ABOVE" (the F of a pair) drops the flag, which puts a cutting F below everything else: the pair's result is then ONE min.
         u32 upT[6], downT[6];
         {
             u32 cur = FAST_KNONE;
             #pragma unroll
-            for (int d = 5; d >= 0; d--) { upT[d] = cur; cur = tr[d] != FAST_KNONE ? tr[d] : cur; }
+            for (int d = 5; d >= 0; d--) { upT[d] = cur; cur = tr[d] != FAST_KNONE ? (tr[d] & ~D3_CUT) : cur; }
             cur = FAST_KNONE;
             #pragma unroll
             for (int d = 0; d < 6; d++) { downT[d] = cur; cur = tr[d] != FAST_KNONE ? tr[d] : cur; }
@@ -426,10 +429,9 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
         #pragma unroll
         for (int i = 0; i < KPT; i++) {
             const u32 e = own_of<T>(tr, i, sub), u = own_of<T>(upT, i, sub), dn = own_of<T>(downT, i, sub);
-            const bool exact = e != FAST_KNONE, up = u != FAST_KNONE;
-            const u32 F = exact ? e : (up ? u : dn);
-            const u32 G = (!exact && up) ? dn : FAST_KNONE;
-            const u32 w = F < 0x8000u ? F : (min(F, G) & 0x7FFFu);
+            // the dice cube alone if it is on the board; else F = up, G = down: F's cut value if F cuts (flag dropped: the smallest),
+            // else G's if G cuts (flagged: below every key that does not cut), else the smaller minimum; no cube above: down alone
+            const u32 w = (e != FAST_KNONE ? e : min(u, dn)) & 0x1FFFu;
             publish<T>(w, i, wq);
         }
         double v = 0.0;
