@@ -1,5 +1,5 @@
 """One-off soak: lock-step HIP vs CPU oracle on many lanes and steps (all six outputs bit-exact), beyond what tests/ runs.
-usage (GPU box): python tools/soak_parity.py [mcts | predict | r02 | d5]"""
+usage (GPU box): python tools/soak_parity.py [mcts | predict | r02 | d5 | long]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -136,6 +136,27 @@ if len(sys.argv) > 1 and sys.argv[1] == "d5":
     roll(2048, 10, 4, 0, 1024, agent="minimax", agent_max_depth=5, autoreset=False, opponent_policy="minimax", max_depth=5, rng="mt19937")
     roll(2048, 10, 4, 0, 512, agent="minimax", agent_max_depth=6, autoreset=False, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=48, board_size=7)
     print("d5 soak passed")
+
+if len(sys.argv) > 1 and sys.argv[1] == "long":
+    # the round's two new code paths at length: slot-task rollouts (games of a wave drift apart inside a launch) and the closed-form
+    # max_depth 5 / 6 search, several launches deep, large slices against the oracle
+    roll(262144, 60, 3, 100000, 104000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=61)
+    roll(65536, 100, 3, 60000, 63000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=62)
+    roll(65536, 37, 4, 0, 3000, opponent_policy="minimax", max_depth=4, heuristic="min_dist", rng="philox", philox_key=63)
+    roll(70000, 50, 2, 69000, 70000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=64, board_size=8)
+    roll(70000, 40, 2, 0, 1500, opponent_policy="minimax", max_depth=2, heuristic="attk", rng="philox", philox_key=65, board_size=6)
+    roll(65536, 40, 3, 1000, 2500, opponent_policy="minimax", max_depth=5, rng="philox", philox_key=66)
+    roll(150000, 25, 2, 149000, 150000, opponent_policy="minimax", max_depth=6, rng="philox", philox_key=67)
+    roll(66000, 30, 2, 0, 1000, opponent_policy="minimax", max_depth=5, heuristic="attk", rng="philox", philox_key=68, board_size=7)
+    roll(140000, 40, 1, 0, 3000, autoreset=False, opponent_policy="minimax", max_depth=3, rng="mt19937")
+    for S, n in ((5, 200000), (6, 100000), (7, 100000), (8, 100000)):
+        b, d = positions(S, 3, n, 12000 + S, max_steps=14 if S == 5 else 26)
+        t0 = time.time()
+        acts, vals = ea.predict_minimax(b, d, 5, "hybrid")
+        oa, ov, _ = po.predict_minimax(b, d, 5, "hybrid")
+        assert np.array_equal(acts.cpu().numpy(), oa) and np.array_equal(bits(vals.cpu().numpy()), bits(ov)), S
+        print("ok predict S=%d depth=5 positions=%d (%.1f s)" % (S, n, time.time() - t0), flush=True)
+    print("long soak passed")
 
 if len(sys.argv) > 1 and sys.argv[1] == "r02":
     # round 2 paths: shaped env and integer heuristics on the table-driven kernel, K-step rollouts (ewn_step_k)
