@@ -83,11 +83,12 @@ struct FastTab {
 // (level, count); 'two_min_dist' needs the second-nearest cube as well and stays on the generic kernels)
 // The fourth image serves 'two_min_dist' (sum of each side's two smallest distances, envs/minimax_ewn.py:133-178): a side's index is
 // that SUM (0 .. 2(S-1)) instead of (level, count), the image's `lvl` table holds distances instead of levels, and the search
-// looks at a mask's two highest bits (template parameter H2 of d3_search / d5_search: the lane-sharing step and rollout kernels
-// are not instantiated with it; the stateless predict kernel and the one-thread-per-game step kernel are).
+// looks at a mask's two highest bits (template parameter H2 of d3_search / d5_search: the stateless predict kernel and the fused
+// step kernel k_step_d3 are instantiated with it, the K-step rollout kernels are not).
 #define FAST_HEUR_IMAGES 4
 static inline int fast_heur_image(int heur) { return heur == 0 ? 0 : (heur == 1 ? 1 : (heur == 3 ? 2 : (heur == 2 ? 3 : -1))); }
 static inline bool fast_heur_lean(int heur) { return heur == 0 || heur == 1 || heur == 3; } // images k_step_d3 / k_rollout_d3 can run
+static inline bool fast_heur_step(int heur) { return fast_heur_lean(heur) || heur == 2; }   // images k_step_d3 can run ('two_min_dist': its own instances)
 
 // LDS / device image size: the struct padded to 4 KiB so the LDS-DMA copy needs no tail handling
 #define FAST_TAB_BYTES(S) ((int)((sizeof(FastTab<S>) + 4095) / 4096 * 4096))

@@ -156,6 +156,9 @@ static inline int rollout_threads_per_game(int n_games)
 // ewn_step_d3.hip: the lean table-driven step kernel (one launch = one env step)
 int ewn_launch_step_d3(const ewn_config *cfg, const Geom &g, const KCfg &k, const ewn_state *st, const void *tables, const int8_t *actions,
                        const ewn_step_out *out, void *scratch, bool lean_random, bool fused_refill, hipStream_t s);
+// ewn_step_d3_h2.hip: the same for the 'two_min_dist' table image
+int ewn_launch_step_d3_h2(const ewn_config *cfg, const Geom &g, const KCfg &k, const ewn_state *st, const void *tables, const int8_t *actions,
+                          const ewn_step_out *out, void *scratch, bool lean_random, bool fused_refill, hipStream_t s);
 
 // ewn_rollout_s<S>.hip: K env steps per launch (ewn_rollout.hpp), one unit per board size
 struct RollCfg;

@@ -870,11 +870,12 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
                           cfg->max_depth <= 6 && fast_heur_image(cfg->heuristic) >= 0;
         const bool lean_random = st->tables && fast_tables_bytes(g.S, g.L) > 0 && cfg->opponent_kind == EWN_OPP_RANDOM;
         if (fast) ks.tables = fast_image(st->tables, g.S, g.L, cfg->max_depth, cfg->heuristic); // the image of this heuristic and depth class
-        if (((fast && fast_heur_lean(cfg->heuristic)) || lean_random) && d3_threads_per_game(k.N) > 0) {
+        if (((fast && fast_heur_step(cfg->heuristic)) || lean_random) && d3_threads_per_game(k.N) > 0) {
             // the lean fused kernel: canonical ring space end to end, T lanes per game (ewn_step_d3.hpp / ewn_step_d3.hip).
             // MT kind with auto-reset: window refills are extra blocks of the same launch (needs the caller's scratch).
             const bool fused_refill = refill && scratch != nullptr;
-            rc = ewn_launch_step_d3(cfg, g, k, st, ks.tables, actions, out, scratch, lean_random, fused_refill, s);
+            if (fast && cfg->heuristic == EWN_H_TWO_MIN_DIST) rc = ewn_launch_step_d3_h2(cfg, g, k, st, ks.tables, actions, out, scratch, false, fused_refill, s);
+            else rc = ewn_launch_step_d3(cfg, g, k, st, ks.tables, actions, out, scratch, lean_random, fused_refill, s);
             if (rc || fused_refill) return rc;
         } else if (fast) {
             const size_t base = (lds + 15) & ~(size_t)15;
@@ -951,7 +952,7 @@ int ewn_lanes_per_game(const ewn_config *cfg, int entry)
     }
     if (entry != 0) return EWN_EINVAL;
     const bool tab = fast_tables_bytes(g.S, g.L) > 0;
-    const bool fast = tab && cfg->opponent_kind == EWN_OPP_MINIMAX && cfg->max_depth <= 6 && fast_heur_lean(cfg->heuristic);
+    const bool fast = tab && cfg->opponent_kind == EWN_OPP_MINIMAX && cfg->max_depth <= 6 && fast_heur_step(cfg->heuristic);
     const bool lean_random = tab && cfg->opponent_kind == EWN_OPP_RANDOM;
     if (!(fast || lean_random) || d3_threads_per_game(k.N) <= 0) return 0;
     if (lean_random || cfg->max_depth < 3) return 1;

@@ -256,7 +256,8 @@ template <int T> EWN_DEV void publish(u32 mine, int i, u32 (&out)[6])
 // arithmetic), two v_bcnt with the level as their accumulate operand, a shift + v_lshl_or for the byte address of the rank, one
 // v_and_or for the root-invariant exceptions; ranks travel as byte offsets (8 x rank) so that value reads need no shift either;
 // a cube's result is ONE 16-bit key (the cut-off value if its replies cut, else 0x8000 | minimum) so that the pair selection per
-// dice is a compare, a min and a select; the lanes exchange keys and chosen ranks, never doubles.
+// dice is one min and a select (a cut carries the flag D3_CUT, dropped on the copy that acts as F); the lanes exchange keys and
+// chosen ranks, never doubles.
 // PERLANE (the slot-task rollout kernel, ewn_rollout.hpp): one call searches the three roots of ONE root cube -- slotL = 0: the
 // first cube of the legal list, 1: the second -- and carries best / bflag / bdir in and out, so that a game whose dice selects a
 // single cube (most do) is finished after one call; returns through `have_second` whether the list has a second cube.
@@ -399,7 +400,7 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
                 // (`worst <= alpha`, minimax.py:59-61; alpha = best so far), 0 if it would not.  The running minimum along a
                 // cube's replies is non-increasing (a0 >= p1 >= p2), so the loop stops at the first of them that is <= alpha.
                 // (three independent selects, last one wins: written as a nested conditional the compiler branches on it)
-                // The cube's key: its cut value if it cuts, else 0x8000 | its minimum.  A cube that is off the board (or was just
+                // The cube's key: D3_CUT | its cut value if it cuts, else 0x8000 | its minimum.  A cube that is off the board (or was just
                 // captured by the root move) reads garbage leaves above: its key is forced to "no such cube" here.
                 u32 key = 0x8000u | p2[ii];
                 key = v2[ii] <= best ? (p2[ii] | D3_CUT) : key;
@@ -641,7 +642,8 @@ static __global__ void k_mtq_flip(u32 *ctrl) { if (threadIdx.x == 0 && blockIdx.
 
 // OPP 0: ExpectiMinimaxAgent(max_depth=3, 'hybrid') reply;  OPP 1: RandomAgent reply (classical_policies/random_policy.py:11-15)
 // RNGK: the dice RNG kind as a compile-time constant, so each instantiation carries only its own generator's registers
-template <int S, int T, int OPP, int RNGK>
+// H2: the 'two_min_dist' table image (a side's index is the sum of its two smallest distances, ewn_fast.hpp)
+template <int S, int T, int OPP, int RNGK, bool H2 = false>
 __global__ __launch_bounds__(D3_BS, (OPP == 2 ? 2 : 1)) void k_step_d3(D3Cfg c, D3Buf B) // max_depth 5 / 6: held to 256 registers (two waves per SIMD)
 {
     constexpr int CELLS = S * S, GPB = D3_BS / T; // games per block
@@ -763,8 +765,8 @@ __global__ __launch_bounds__(D3_BS, (OPP == 2 ? 2 : 1)) void k_step_d3(D3Cfg c, 
     // the opponent's search: run by every lane (lanes without a pending reply compute on a harmless state),
     // so the DPP exchanges inside always see their partners
     int oflag = 0, odir = 0;
-    if constexpr (OPP == 0) d3_search<S, T>(Tb, s, dice, sub, c.depth, oflag, odir);
-    if constexpr (OPP == 2) d5_dispatch<S, (T > 2 ? 2 : T)>(Tb, s, dice, sub, oflag, odir); // max_depth 5 / 6: its own instances (T = 1, 2), so its registers do not weigh on the others
+    if constexpr (OPP == 0) d3_search<S, T, H2>(Tb, s, dice, sub, c.depth, oflag, odir);
+    if constexpr (OPP == 2) d5_dispatch<S, (T > 2 ? 2 : T), H2>(Tb, s, dice, sub, oflag, odir); // max_depth 5 / 6: its own instances (T = 1, 2), so its registers do not weigh on the others
     if (reply) {
         // opponent half, envs/ewn.py:464-486
         const u32 e = pk_sel<S>(Tb, s.posP, dice);

@@ -204,6 +204,24 @@ def test_step_minimax_opponent_vs_oracle(ea, depth, heur):
     assert _lockstep(ea, 1500, 30, opponent_policy="minimax", max_depth=depth, heuristic=heur, rng="mt19937") > 1000
 
 
+@pytest.mark.parametrize("N,steps,kw", [
+    (900, 25, dict(max_depth=3, rng="mt19937")), (900, 20, dict(max_depth=4, rng="philox", philox_key=9)), (900, 20, dict(max_depth=2, rng="philox")),
+    (40000, 10, dict(max_depth=3, rng="philox", philox_key=3)), (132000, 5, dict(max_depth=3, rng="philox", philox_key=4)),
+    (160, 10, dict(max_depth=5, rng="mt19937")), (160, 8, dict(max_depth=6, rng="philox", philox_key=6)), (33000, 4, dict(max_depth=5, rng="philox", philox_key=7)),
+    (700, 20, dict(max_depth=3, rng="philox", board_size=7)), (500, 16, dict(max_depth=4, rng="mt19937", board_size=8)),
+    (600, 25, dict(max_depth=3, rng="philox", shaped=True, reward=10.0, illegal_move_tolerance=3)),
+], ids=lambda v: str(v) if isinstance(v, int) else "-".join("%s=%s" % kv for kv in sorted(v.items())))
+def test_two_min_dist_on_the_fused_step_kernel(ea, N, steps, kw):
+    """'two_min_dist' (envs/minimax_ewn.py:133-178) on k_step_d3's own instances: four, two and one lane(s) per game, every depth class,
+    both dice kinds, larger boards, the shaped env -- lock step with the oracle."""
+    import ctypes as C
+    from ewn_gym_amd import _lib
+    probe = ea.VecEWN(N, opponent_policy="minimax", heuristic="two_min_dist", autoreset=True, **kw)
+    assert _lib.load().ewn_lanes_per_game(C.byref(probe.cfg), 0) > 0   # the table-driven kernel, not the generic one
+    del probe
+    _lockstep(ea, N, steps, opponent_policy="minimax", heuristic="two_min_dist", **kw)
+
+
 def test_step_minimax_depth4_5_vs_oracle(ea):
     _lockstep(ea, 200, 12, opponent_policy="minimax", max_depth=4, rng="philox", philox_key=5)
     _lockstep(ea, 64, 10, opponent_policy="minimax", max_depth=5, rng="mt19937")
