@@ -1,5 +1,5 @@
 """Command-line counterpart of the reference's train.py (argument names follow train.py:162-259
-where they apply): A2C on VecEWN lanes instead of SubprocVecEnv workers, per-epoch evaluation
+where they apply): A2C (or PPO: `python -m ewn_gym_amd.train_a2c PPO ...`) on VecEWN lanes instead of SubprocVecEnv workers, per-epoch evaluation
 against minimax on the un-shaped env (train.py:66-117), best-model checkpointing.
 
   python -m ewn_gym_amd.train_a2c --num_envs 4096 --epoch_num 10 --timesteps_per_epoch 200000
@@ -21,7 +21,10 @@ from .vec_env import VecEWN
 def main():
     ap = argparse.ArgumentParser(description="Trainer for EWN on VecEWN lanes (counterpart of the reference's train.py)")
     # train.py:174-184 selects the algorithm with a sub-command; A2C is the one built here
-    ap.add_argument("algorithm", nargs="?", default="A2C", choices=["A2C", "PPO"], help="A2C (PPO is refused: not built)")
+    ap.add_argument("algorithm", nargs="?", default="A2C", choices=["A2C", "PPO"], help="train.py:174-184's sub-command")
+    ap.add_argument("--batch_size", "-b", type=int, default=None,
+                    help="PPO: minibatch size in samples of the n_steps x lanes rollout buffer (default: a quarter of it; train.py:178-183)")
+    ap.add_argument("--n_epochs", type=int, default=10, help="PPO: passes over the rollout buffer per update (SB3 default)")
     ap.add_argument("--checkpoint", default=None, help="path of a checkpoint written by this trainer to resume from (train.py:137-139, 248-251)")
     ap.add_argument("--model_seed", type=int, default=None, help="seed of the policy initialisation and sampling (default: --env_seed)")
     ap.add_argument("--num_envs", "-ne", type=int, default=4096, help="lanes per GPU")
@@ -43,11 +46,6 @@ def main():
     ap.add_argument("--seed", "--env_seed", dest="seed", type=int, default=9487)
     ap.add_argument("--save_dir", default="models")
     a = ap.parse_args()
-    if a.algorithm == "PPO":
-        # train.py:178-183, 50-62: SB3's PPO (clipped surrogate, minibatch epochs, GAE 0.95).  Only the A2C update is built on
-        # the device-resident rollout; refusing is better than silently training something else under that name.
-        ap.error("PPO is not built in this trainer (only the A2C sub-command of train.py:174-184 is); use A2C")
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world > 1:
@@ -61,7 +59,12 @@ def main():
                  illegal_move_tolerance=a.illegal_move_tolerance, autoreset=True, lane_offset=lo,
                  seed_stride=a.num_envs * world, philox_key=a.seed, shaped_refresh_on_reset=not a.reference_quirks)
     env.reset(seeds=lane_seeds(lo, hi, a.seed).cuda())
-    trainer = A2CTrainer(env, n_steps=a.n_steps, learning_rate=a.learning_rate, seed=a.seed if a.model_seed is None else a.model_seed)
+    mseed = a.seed if a.model_seed is None else a.model_seed
+    if a.algorithm == "PPO":   # train.py:39-49: SB3's PPO with batch_size and learning_rate given, the rest at its defaults (ewn_gym_amd/ppo.py)
+        from .ppo import PPOTrainer
+        trainer = PPOTrainer(env, n_steps=a.n_steps, batch_size=a.batch_size, n_epochs=a.n_epochs, learning_rate=a.learning_rate, seed=mseed)
+    else:
+        trainer = A2CTrainer(env, n_steps=a.n_steps, learning_rate=a.learning_rate, seed=mseed)
     if a.checkpoint is not None:      # train.py:137-139: resume the model (and here the optimiser and the step counter too)
         trainer.load(a.checkpoint)
         if rank == 0:

@@ -133,3 +133,63 @@ def test_ranks_share_parameters_but_not_sampling_noise():
         t._rollout()
     assert torch.equal(a._acts, a2._acts)          # same shard, same seed: reproducible
     assert not torch.equal(a._acts, b._acts)       # other shard: other noise
+
+
+class _NoisyEnv(_FakeEnv):
+    """... with observations, rewards and episode ends that vary, so that advantages and log-probabilities are not degenerate"""
+
+    def __init__(self, n, lane_offset):
+        super().__init__(n, lane_offset)
+        self.g = torch.Generator().manual_seed(7 + lane_offset)
+
+    def step(self, a):
+        self.board = torch.randint(-6, 7, (self.N, 5, 5), generator=self.g).to(torch.int8)
+        self.dice = torch.randint(1, 7, (self.N,), generator=self.g).to(torch.int8)
+        r = torch.randn(self.N, generator=self.g, dtype=torch.float64)
+        t = (torch.rand(self.N, generator=self.g) < 0.2).to(torch.uint8)
+        return self.board, self.dice, r, t, self._t, self._t
+
+
+def test_ppo_first_step_is_the_a2c_policy_gradient_and_clipping_bites_later():
+    """With one epoch, ONE minibatch (the whole buffer) and no advantage normalisation the probability ratio is 1 everywhere at the
+    first optimiser step, so PPO's clipped surrogate has A2C's policy gradient (train.py:39-49: SB3 PPO; maths only, parity unpinned).
+    After several epochs on the same buffer the ratio leaves [1 - clip, 1 + clip] for some samples and their gradient vanishes."""
+    from ewn_gym_amd.a2c import n_step_returns
+    from ewn_gym_amd.ppo import PPOTrainer
+    T, N = 4, 96
+    tr = PPOTrainer(_NoisyEnv(N, 0), n_steps=T, batch_size=T * N, n_epochs=1, normalize_advantage=False, seed=11, use_graph=False,
+                    learning_rate=1e-2)
+    tr._rollout()
+    boards, dices, acts = tr._boards.reshape(T * N, 5, 5), tr._dices.reshape(T * N), tr._acts.reshape(T * N, 2)
+    with torch.no_grad():
+        _, _, lv = tr.model(tr.env.board, tr.env.dice)
+        adv, ret = n_step_returns(tr._rews, tr._vals, tr._dones, lv, tr.gamma, tr.gae_lambda)
+        old_logp, _, _ = tr.model.evaluate_actions(boards, dices, acts)
+    adv, ret = adv.reshape(-1), ret.reshape(-1)
+    loss, pl, vl, en, cf = tr.ppo_loss(boards, dices, acts, old_logp, adv, ret)
+    assert float(cf) == 0.0
+    tr.model.zero_grad()
+    loss.backward()
+    g_ppo = torch.cat([p.grad.reshape(-1) for p in tr.model.parameters()]).clone()
+    logp, ent, value = tr.model.evaluate_actions(boards, dices, acts)
+    a2c = -(adv * logp).mean() + tr.vf_coef * torch.nn.functional.mse_loss(ret, value)
+    tr.model.zero_grad()
+    a2c.backward()
+    g_a2c = torch.cat([p.grad.reshape(-1) for p in tr.model.parameters()])
+    assert torch.allclose(g_ppo, g_a2c, rtol=1e-4, atol=1e-6)
+    # many passes over one buffer: the policy moves, ratios leave the trust region, the clip fraction becomes positive
+    tr2 = PPOTrainer(_NoisyEnv(N, 0), n_steps=T, batch_size=T * N // 2, n_epochs=30, seed=11, use_graph=False, learning_rate=3e-2)
+    p0 = [p.detach().clone() for p in tr2.model.parameters()]
+    st = tr2.collect_and_update()
+    assert torch.isfinite(st).all() and tr2.num_timesteps == T * N
+    assert any(not torch.equal(a, b) for a, b in zip(p0, tr2.model.parameters()))
+    with torch.no_grad():
+        new_logp, _, _ = tr2.model.evaluate_actions(tr2._boards.reshape(T * N, 5, 5), tr2._dices.reshape(T * N), tr2._acts.reshape(T * N, 2))
+    assert float((new_logp.exp().sum())) > 0.0
+
+
+def test_ppo_rejects_a_minibatch_larger_than_the_buffer():
+    import pytest
+    from ewn_gym_amd.ppo import PPOTrainer
+    with pytest.raises(ValueError):
+        PPOTrainer(_FakeEnv(8, 0), n_steps=2, batch_size=17, use_graph=False)

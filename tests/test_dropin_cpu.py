@@ -67,13 +67,14 @@ def test_spaces_compat():
     assert d.contains(1) and d.contains(7) and not d.contains(0) and not d.contains(8)
 
 
-def test_trainer_cli_refuses_ppo_and_accepts_the_reference_flag_names():
-    """train.py:174-184: the algorithm is a sub-command; only A2C is built, PPO must be refused, not silently replaced"""
+def test_trainer_cli_has_both_sub_commands_and_the_reference_flag_names():
+    """train.py:174-184: the algorithm is a sub-command, A2C or PPO (`-b/--batch_size` belongs to PPO, train.py:178-183); anything
+    else is refused by the parser"""
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, "-m", "ewn_gym_amd.train_a2c", "PPO"], cwd=ROOT, capture_output=True, text=True)
-    assert r.returncode == 2 and "PPO is not built" in r.stderr
+    r = subprocess.run([sys.executable, "-m", "ewn_gym_amd.train_a2c", "DQN"], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 2 and "invalid choice" in r.stderr
     h = subprocess.run([sys.executable, "-m", "ewn_gym_amd.train_a2c", "--help"], cwd=ROOT, capture_output=True, text=True).stdout
     for flag in ("--checkpoint", "--env_seed", "--model_seed", "--num_envs", "--n_steps", "--timesteps_per_epoch", "--illegal_move_tolerance",
-                 "--opponent_policy", "--max_depth", "--epoch_num", "--learning_rate"):
+                 "--opponent_policy", "--max_depth", "--epoch_num", "--learning_rate", "--batch_size", "--n_epochs"):
         assert flag in h, flag

@@ -78,6 +78,36 @@ def test_a2c_learns_to_avoid_illegal_moves():
     assert after < 0.6 * before, (before, after)
 
 
+def test_ppo_learns_to_avoid_illegal_moves():
+    """train.py's PPO sub-command on the device-resident rollout (ewn_gym_amd/ppo.py; SB3 defaults, parity unpinned)"""
+    import ewn_gym_amd as ea
+    from ewn_gym_amd.ppo import PPOTrainer
+    N = 4096
+    env = ea.VecEWN(N, opponent_policy="random", rng="philox", shaped=True, reward=10.0, illegal_move_reward=-1.0,
+                    illegal_move_tolerance=10, autoreset=True, shaped_refresh_on_reset=True, philox_key=2)
+    env.reset(seeds=torch.arange(N, dtype=torch.int32))
+    tr = PPOTrainer(env, n_steps=8, n_epochs=4, learning_rate=1e-3, seed=0)
+
+    def illegal_rate(steps=12):
+        bad = tot = 0
+        for _ in range(steps):
+            a, _ = tr.model.act(env.board, env.dice, deterministic=False, generator=tr.gen)
+            info = env.step(a)[5]
+            bad += int(((info == 1) | (info == 5)).sum().item())
+            tot += N
+        return bad / tot
+
+    before = illegal_rate()
+    stats = None
+    for _ in range(40):
+        stats = tr.collect_and_update()
+    after = illegal_rate()
+    stats = tr.stats_dict(stats)
+    assert all(np.isfinite(v) for v in stats.values())
+    assert tr.num_timesteps == 40 * 8 * N
+    assert after < 0.6 * before, (before, after)
+
+
 def test_checkpoint_resume(tmp_path):
     """train.py:137-139 / --checkpoint: a saved trainer resumes with the same parameters, optimiser state and step count"""
     import ewn_gym_amd as ea
