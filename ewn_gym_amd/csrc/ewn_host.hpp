@@ -113,18 +113,20 @@ static inline int64_t fast_tables_bytes(int S, int L)
 }
 
 // Lanes of one wavefront that share a game in k_step_d3: enough to put several waves on every SIMD
-// (1024 SIMDs x 64 lanes) at the given number of games.  EWN_D3_T=0 disables the kernel, 1/2/4 forces T.
+// (1024 SIMDs x 64 lanes) at the given number of games.  EWN_D3_T=0 disables the kernel, 1 / 2 forces T.
 static inline int d3_threads_per_game(int n_games)
 {
     static const int forced = [] { const char *e = getenv("EWN_D3_T"); return e ? atoi(e) : -1; }();
-    if (forced == 0 || forced == 1 || forced == 2 || forced == 4) return forced;
+    if (forced == 0 || forced == 1 || forced == 2) return forced;
     // measured on MI355X (tools/sweep_T.sh, us per step, T = 1 / 2 / 4): 16 384 games 14.9 / 10.9 / 10.0; 32 768: 15.1 / 11.3 / 12.6;
     // 65 536: 15.8 / 14.8 / 18.7; 131 072: 21.6 / 22.4 / 32.3; 262 144: 36.3 / 39.4 / 57.5; 1 048 576: 118 / 132 / 205.
     // The kernel is bound by integer VALU issue once the chip is full, so lanes added beyond what hides the LDS/global
     // latency only add redundant instructions.
+    // Re-measured at the end of round 2 (table-driven setup, one-min pair selection): two lanes per game are now as fast as or faster
+    // than four at every lane count below 131 072 (2 048 .. 24 576 games: one-step launch 9.9-10.4 us against 10.1-12.1), so the
+    // four-lanes-per-game instances were dropped from the library (d3_search keeps its T = 4 code: `own_of` / `publish`).
     if (n_games >= 131072) return 1;
-    if (n_games >= 32768) return 2;
-    return 4;
+    return 2;
 }
 
 // the lean kernel's MT refill hand-off (ewn_core.hpp MtQueue): ctrl[4] | cnt[2][nb4] | list[2][nblk][2 * games per block] x 16 B.
@@ -147,10 +149,10 @@ static inline int64_t mtq_bytes(int64_t N)
 static inline int rollout_threads_per_game(int n_games)
 {
     static const int forced = [] { const char *e = getenv("EWN_ROLLOUT_T"); return e ? atoi(e) : -1; }();
-    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    if (forced == 1 || forced == 2) return forced;
+    // measured (us per step with the trajectory, T = 2 / 4): 2 048 games 6.46 / 6.93, 8 192: 6.56 / 7.11, 24 576: 6.79 / 8.45
     if (n_games >= 131072) return 1;
-    if (n_games >= 32768) return 2;
-    return 4;
+    return 2;
 }
 
 // ewn_step_d3.hip: the lean table-driven step kernel (one launch = one env step)

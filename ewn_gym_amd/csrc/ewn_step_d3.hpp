@@ -8,7 +8,7 @@
 //    the search.  The agent is the canonical BOTTOM_RIGHT side ("replier" geometry), the
 //    opponent the canonical TOP_LEFT side; an action [flag, dir] means the same in both
 //    views (envs/ewn.py:289-296);
-//  * T lanes cooperate on one game (T = 1, 2, 4): each computes a share of the 108 leaves
+//  * T lanes cooperate on one game (the code is written for T = 1, 2, 4; the library instantiates 1 and 2): each computes a share of the 108 leaves
 //    and of the 36 (root, dice) scans and they swap results with DPP lane permutes inside
 //    the wavefront.  At 65 536 lanes a thread per game is ONE wave per SIMD; T lanes per
 //    game give T waves per SIMD, which is what hides LDS/global latency and doubles the

@@ -128,8 +128,8 @@ def test_default_kernel_selection_is_not_changed_by_the_environment():
     lib = _lib.load()
     lanes = lambda entry, **kw: lib.ewn_lanes_per_game(C.byref(cfg(rng_kind=1, autoreset=1, **kw)), entry)  # noqa: E731
     for entry in (0, 1):
-        assert lanes(entry, opponent_kind=1, n_lanes=1024) == 4
-        assert lanes(entry, opponent_kind=1, n_lanes=32767) == 4
+        assert lanes(entry, opponent_kind=1, n_lanes=1024) == 2
+        assert lanes(entry, opponent_kind=1, n_lanes=32767) == 2
         assert lanes(entry, opponent_kind=1, n_lanes=32768) == 2
         assert lanes(entry, opponent_kind=1, n_lanes=65536) == 2          # the headline configuration
         assert lanes(entry, opponent_kind=1, n_lanes=131071) == 2

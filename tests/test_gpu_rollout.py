@@ -76,7 +76,7 @@ def _rollout_vs_oracle(ea, N, lo, hi, K, launches, agent="random", agent_max_dep
     return int(nep.sum())
 
 
-@pytest.mark.parametrize("N,lo", [(1500, 0), (40000, 30000), (140000, 131000)])   # 4, 2 and 1 lanes per game
+@pytest.mark.parametrize("N,lo", [(1500, 0), (40000, 30000), (140000, 131000)])   # two lanes per game (small and mid-size), one lane per game
 def test_rollout_random_agent_depth3_opponent(ea, N, lo):
     n = _rollout_vs_oracle(ea, N, lo, lo + 384, 9, 3, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=2024)
     assert n > 384     # every lane of the slice went through auto-resets inside the launches

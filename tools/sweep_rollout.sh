@@ -3,7 +3,7 @@
 out=${1:-gpurun_out/sweep_rollout.txt}
 : > $out
 for N in 16384 32768 65536 131072 262144 1048576; do
-  for T in 1 2 4; do
+  for T in 1 2; do
     EWN_ROLLOUT_T=$T python3 bench.py --no-cpu-baseline --no-extras --lanes $N --steps 400 --warmup 50 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][0]); print('N=$N T=$T traj   %.4g steps/s  %.2f us/step' % (d['value'], d['ms_per_step']*1e3))" >> $out
