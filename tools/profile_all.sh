@@ -1,0 +1,23 @@
+#!/bin/bash
+# usage (GPU box, from the repo root): tools/profile_all.sh <tag>     e.g.  gpurun -- 'tools/profile_all.sh r03'
+# Everything profiles/<round>/ is made from, in one call (~6 GPU-minutes): rocprofv3 kernel stats + PMC passes of the headline bench
+# in its launch shapes and of the max_depth 5 rollout, the lane-count / opponent sweep, the evaluation wall times, the soak logs and
+# the two bench lines.  Afterwards, in the build container:
+#   hipcc -S --cuda-device-only ... ewn_rollout_s5.hip / ewn_step_d3.hip; cat them > /tmp/both.s
+#   python tools/isa_mix.py --asm /tmp/both.s --kernel <names> --out profiles/<round>/isa_mix.json
+#   python tools/make_pmc_traffic.py gpurun_out/<tag> profiles/<round>;  python tools/collect_cfg_profile.py gpurun_out/<tag>/d5_k50 profiles/<round>/d5
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+T=${1:-rXX}
+O=gpurun_out/$T
+mkdir -p $R/$O
+timeout -k 10 500 $R/tools/profile_r02.sh $O > $R/$O/profile.log 2>&1; tail -1 $R/$O/profile.log
+timeout -k 10 200 $R/tools/profile_cfg.sh $O d5_k50 --max-depth 5 --steps 150 --warmup 50 | tail -1
+cd $R
+timeout -k 10 300 tools/sweep_rollout.sh $O/sweep_rollout.txt > /dev/null 2>&1; tail -3 $O/sweep_rollout.txt
+timeout -k 10 100 python3 tools/eval_time.py > $O/eval_time.txt 2>&1
+for p in "" mcts predict r02 d5 long; do
+  timeout -k 10 600 python3 tools/soak_parity.py $p > $O/soak_${p:-step}.log 2>&1; echo rc=$? >> $O/soak_${p:-step}.log; tail -2 $O/soak_${p:-step}.log
+done
+timeout -k 10 200 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
+timeout -k 10 120 python3 bench.py --steps 20 --warmup 5 > $O/bench_driver_shape.json 2>/dev/null
+echo all done
