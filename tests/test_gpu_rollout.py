@@ -118,6 +118,12 @@ def test_rollout_slot_task_kernel_every_search(ea, kw):
                        philox_key=1000 + kw["max_depth"], **kw)
 
 
+def test_rollout_slot_task_kernel_short_launches(ea):
+    """K = 1, 2, 3: a launch ends after every game has played exactly K steps, however many of them needed a second iteration"""
+    for K in (1, 2, 3):
+        _rollout_vs_oracle(ea, SLOT_N + 37, 65900, 66037, K, 6, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=70 + K)
+
+
 def test_rollout_slot_task_kernel_frozen_lanes_and_numpy_dice(ea):
     """... without auto-reset (lanes freeze as their episode ends, and go on writing their rows) on the MT19937-compat dice, with
     and without the board column; one lane per game at 140 000 lanes."""
