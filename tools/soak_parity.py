@@ -137,20 +137,21 @@ if len(sys.argv) > 1 and sys.argv[1] == "d5":
     roll(2048, 10, 4, 0, 512, agent="minimax", agent_max_depth=6, autoreset=False, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=48, board_size=7)
     print("d5 soak passed")
 
+SHIFT = int(os.environ.get("SOAK_SHIFT", "0"))   # another set of games for a repeated `long` run
 if len(sys.argv) > 1 and sys.argv[1] == "long":
     # the round's two new code paths at length: slot-task rollouts (games of a wave drift apart inside a launch) and the closed-form
     # max_depth 5 / 6 search, several launches deep, large slices against the oracle
-    roll(262144, 60, 3, 100000, 104000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=61)
-    roll(65536, 100, 3, 60000, 63000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=62)
-    roll(65536, 37, 4, 0, 3000, opponent_policy="minimax", max_depth=4, heuristic="min_dist", rng="philox", philox_key=63)
-    roll(70000, 50, 2, 69000, 70000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=64, board_size=8)
-    roll(70000, 40, 2, 0, 1500, opponent_policy="minimax", max_depth=2, heuristic="attk", rng="philox", philox_key=65, board_size=6)
-    roll(65536, 40, 3, 1000, 2500, opponent_policy="minimax", max_depth=5, rng="philox", philox_key=66)
-    roll(150000, 25, 2, 149000, 150000, opponent_policy="minimax", max_depth=6, rng="philox", philox_key=67)
-    roll(66000, 30, 2, 0, 1000, opponent_policy="minimax", max_depth=5, heuristic="attk", rng="philox", philox_key=68, board_size=7)
+    roll(262144, 60, 3, 100000, 104000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=61 + SHIFT)
+    roll(65536, 100, 3, 60000, 63000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=62 + SHIFT)
+    roll(65536, 37, 4, 0, 3000, opponent_policy="minimax", max_depth=4, heuristic="min_dist", rng="philox", philox_key=63 + SHIFT)
+    roll(70000, 50, 2, 69000, 70000, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=64 + SHIFT, board_size=8)
+    roll(70000, 40, 2, 0, 1500, opponent_policy="minimax", max_depth=2, heuristic="attk", rng="philox", philox_key=65 + SHIFT, board_size=6)
+    roll(65536, 40, 3, 1000, 2500, opponent_policy="minimax", max_depth=5, rng="philox", philox_key=66 + SHIFT)
+    roll(150000, 25, 2, 149000, 150000, opponent_policy="minimax", max_depth=6, rng="philox", philox_key=67 + SHIFT)
+    roll(66000, 30, 2, 0, 1000, opponent_policy="minimax", max_depth=5, heuristic="attk", rng="philox", philox_key=68 + SHIFT, board_size=7)
     roll(140000, 40, 1, 0, 3000, autoreset=False, opponent_policy="minimax", max_depth=3, rng="mt19937")
     for S, n in ((5, 200000), (6, 100000), (7, 100000), (8, 100000)):
-        b, d = positions(S, 3, n, 12000 + S, max_steps=14 if S == 5 else 26)
+        b, d = positions(S, 3, n, 12000 + S + 100 * SHIFT, max_steps=14 if S == 5 else 26)
         t0 = time.time()
         acts, vals = ea.predict_minimax(b, d, 5, "hybrid")
         oa, ov, _ = po.predict_minimax(b, d, 5, "hybrid")
