@@ -316,7 +316,6 @@ __global__ __launch_bounds__(D3_BS, (OPP == 2 ? 2 : 1)) void k_rollout_slots(Rol
     double reward = 0.0, best = 0.0;
     int term = 0, trunc = 0, info = EWN_INFO_NONE, aflag = 0, adir = 0, oflag = 0, odir = 0;
     bool reply = false;
-    #pragma unroll 1
     while (true) {
         const bool pending = live && kdone < c.K;
         if (__builtin_amdgcn_ballot_w64(pending) == 0) break; // this wave's games have all played K steps
