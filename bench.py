@@ -223,7 +223,7 @@ class Runner:
             done = 0
             while done < n_steps:
                 k = min(self.K, n_steps - done)
-                env.rollout(k, agent="random", traj=self.traj)
+                env.rollout(k, agent="sample" if self.agent == "uniform6" else "random", traj=self.traj)
                 done += k
             return
         for _ in range(n_steps):
@@ -348,7 +348,7 @@ def main():
     env = make_env()
     mode = args.mode
     if mode == "auto":
-        mode = "rollout" if (args.agent == "legal" and not args.separate_agent_kernel and env.supports_rollout()) else "step"
+        mode = "rollout" if (not args.separate_agent_kernel and env.supports_rollout("sample" if args.agent == "uniform6" else "random")) else "step"
     runner = Runner(torch, env, args, mode, trajectory=not args.no_trajectory, agent=args.agent)
     runner.launch(args.warmup)                                   # W untimed warm-up steps
     # Clock warm-up.  Between the warm-up steps and the timed region the host captures, instantiates and uploads the graph(s): the
@@ -401,7 +401,11 @@ def main():
             if not args.no_trajectory:
                 extra("rollout_without_trajectory", "rollout", trajectory=False)
         if args.agent == "legal":
-            extra("agent_uniform_over_all_6_actions", "step", agent="uniform6")   # illegal-move terminations
+            # illegal-move terminations.  In the engine (ewn_step_k's EWN_AGENT_SAMPLE = env.action_space.sample()) when the
+            # configuration has a rollout kernel, and as a torch policy in front of one ewn_step per step (rand + cast + copy) either way
+            if env.supports_rollout("sample"):
+                extra("agent_uniform_over_all_6_actions", "rollout", agent="uniform6")
+            extra("agent_uniform_over_all_6_actions_torch_policy", "step", agent="uniform6")
 
     if rank == 0:
         total_steps = N * world * args.steps
@@ -446,7 +450,7 @@ def main():
         else:
             launch = "one ewn_step launch per env step; " + ("hipGraph replay (%s)" % ", ".join("%d x %d steps" % (r, g) for g, r in runner.plan(args.steps))
                                                              if not args.no_graph else "eager")
-        agent_txt = {"legal": "random-legal agent", "uniform6": "agent uniform over all 6 actions"}[args.agent]
+        agent_txt = {"legal": "random-legal agent", "uniform6": "agent uniform over all 6 actions (env.action_space.sample())"}[args.agent]
         line = {
             "metric": "env steps/sec (whole node), 5x5 EWN, depth-3 expectiminimax opponent" if
                       (args.board_size == 5 and args.opponent == "minimax" and args.max_depth == 3) else

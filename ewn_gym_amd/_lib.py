@@ -24,7 +24,7 @@ EXPORTS = ["ewn_abi_version", "ewn_strerror", "ewn_rng_words", "ewn_step_scratch
            "ewn_build_tables", "ewn_init_aux", "ewn_reset",
            "ewn_step", "ewn_legal_actions", "ewn_apply_action", "ewn_playout_wins", "ewn_evaluate", "ewn_predict_minimax", "ewn_predict_random",
            "ewn_predict_mcts", "ewn_step_k", "ewn_step_k_supported", "ewn_predict_minimax_sim", "ewn_lanes_per_game"]
-AGENT = {"random": 0, "minimax": 1}
+AGENT = {"random": 0, "minimax": 1, "sample": 2}   # "sample": env.action_space.sample(), all six actions (EWN_AGENT_SAMPLE)
 
 
 class EwnConfig(C.Structure):  # struct ewn_config
@@ -108,7 +108,7 @@ def load():
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.ewn_abi_version() != 2:
+    if lib.ewn_abi_version() != 3:
         raise EwnError("libewn_hip.so ABI version mismatch")
     _lib = lib
     return lib

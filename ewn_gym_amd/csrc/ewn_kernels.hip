@@ -923,7 +923,7 @@ static int rollout_plan(const ewn_config *cfg, const Geom &g, const KCfg &k, int
     if (cfg->opponent_kind == EWN_OPP_RANDOM) opp = 1;
     else if (cfg->opponent_kind == EWN_OPP_MINIMAX && fast_heur_lean(cfg->heuristic)) opp = cfg->max_depth > 4 ? 2 : 0;
     else return EWN_EUNSUPPORTED;
-    if (agent_kind == EWN_AGENT_RANDOM) agent = 0;
+    if (agent_kind == EWN_AGENT_RANDOM || agent_kind == EWN_AGENT_SAMPLE) agent = 0;
     else if (agent_kind == EWN_AGENT_MINIMAX) {
         if (agent_max_depth < 1) return EWN_EINVAL;
         if (agent_max_depth > EWN_MAX_DEPTH) return EWN_EUNSUPPORTED;
@@ -981,7 +981,7 @@ int ewn_step_k(const ewn_config *cfg, const ewn_state *st, int K, int agent_kind
     int T, opp, agent;
     rc = rollout_plan(cfg, g, k, agent_kind, agent_max_depth, T, opp, agent);
     if (rc) return rc;
-    RollCfg rcf = { k.N, k.autoreset, k.lane_offset, k.depth, agent_max_depth, K, k.seed_stride, k.W, k.reward, k.key };
+    RollCfg rcf = { k.N, k.autoreset, k.lane_offset, k.depth, agent_max_depth, K, agent_kind == EWN_AGENT_SAMPLE ? 1 : 0, k.seed_stride, k.W, k.reward, k.key };
     RollBuf rb;
     memset(&rb, 0, sizeof(rb));
     rb.board = st->board; rb.dice = st->dice; rb.done = st->done; rb.rng = st->rng;

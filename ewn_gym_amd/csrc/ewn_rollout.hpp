@@ -27,6 +27,7 @@
 
 struct RollCfg {
     int N, autoreset, lane_offset, depth, agent_depth, K;  // depth / agent_depth: max_depth of the opponent's / the agent's search
+    int agent_sample;                                      // AGENT 0 only: 1 = action_space.sample() (uniform over all six actions) instead of RandomAgent
     u32 seed_stride, W;
     double reward;
     u64 key;
@@ -134,8 +135,12 @@ __global__ __launch_bounds__(D3_BS, ((OPP == 2 || AGENT == 2) ? 2 : 1)) void k_r
             const u32 e = pk_sel<S>(Tb, s.posN, dice), pp = pk_pair(s.posN, e);
             const u32 okm = (u32)Tb->lgn[pp & 0xFFu] | ((u32)Tb->lgn[pp >> 8] << 3);
             const int n = __popc(okm);
-            if (n > 0) {
-                const u32 w = agent_hash(r.seed_mix(), r.draws(), (u32)(c.lane_offset + game), c.key);
+            const u32 w = agent_hash(r.seed_mix(), r.draws(), (u32)(c.lane_offset + game), c.key);
+            if (c.agent_sample) { // env.action_space.sample(): one of the six (flag, direction) pairs, legal or not
+                const int a6 = (int)__umulhi(w, 6u);
+                aflag = a6 >= 3 ? 1 : 0;
+                adir = a6 - 3 * aflag;
+            } else if (n > 0) {
                 const int slot = Tb->nth[okm * 8u + __umulhi(w, (u32)n)];
                 aflag = slot < 3 ? (int)(e >> 15) : 0;
                 adir = slot < 3 ? slot : slot - 3;
@@ -328,8 +333,12 @@ __global__ __launch_bounds__(D3_BS, (OPP == 2 ? 2 : 1)) void k_rollout_slots(Rol
             const u32 e = pk_sel<S>(Tb, s.posN, dice), pp = pk_pair(s.posN, e);
             const u32 okm = (u32)Tb->lgn[pp & 0xFFu] | ((u32)Tb->lgn[pp >> 8] << 3);
             const int n = __popc(okm);
-            if (n > 0) {
-                const u32 w = agent_hash(r.seed_mix(), r.draws(), (u32)(c.lane_offset + game), c.key);
+            const u32 w = agent_hash(r.seed_mix(), r.draws(), (u32)(c.lane_offset + game), c.key);
+            if (c.agent_sample) { // env.action_space.sample(): one of the six (flag, direction) pairs, legal or not
+                const int a6 = (int)__umulhi(w, 6u);
+                aflag = a6 >= 3 ? 1 : 0;
+                adir = a6 - 3 * aflag;
+            } else if (n > 0) {
                 const int sl = Tb->nth[okm * 8u + __umulhi(w, (u32)n)];
                 aflag = sl < 3 ? (int)(e >> 15) : 0;
                 adir = sl < 3 ? sl : sl - 3;

@@ -168,7 +168,8 @@ class VecEWN:
                 "n_episodes": torch.zeros(N, dtype=torch.int32, device=dev), "n_wins": torch.zeros(N, dtype=torch.int32, device=dev)}
 
     def rollout(self, K, agent="random", agent_max_depth=3, traj=None, totals=None):
-        """Play K steps of every lane in one launch, the agent being RandomAgent or ExpectiMinimaxAgent(agent_max_depth).
+        """Play K steps of every lane in one launch, the agent being RandomAgent ("random"), ExpectiMinimaxAgent(agent_max_depth)
+        ("minimax") or env.action_space.sample() ("sample": all six actions, illegal ones included).
         traj: dict from alloc_rollout (first dimension >= K) or None; totals: dict from alloc_totals or None."""
         traj, totals = traj or {}, totals or {}
         for v in traj.values():

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EWN_ABI_VERSION 2 /* 2: ewn_step_k, ewn_predict_minimax_sim, ewn_lanes_per_game; six table images; boards up to 11x11 */
+#define EWN_ABI_VERSION 3 /* 2: ewn_step_k, ewn_predict_minimax_sim, ewn_lanes_per_game; six table images; boards up to 11x11.  3: EWN_AGENT_SAMPLE; 32 KB table images */
 
 /* error codes */
 #define EWN_OK 0
@@ -178,6 +178,8 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
 #define EWN_AGENT_RANDOM 0  /* RandomAgent.predict (classical_policies/random_policy.py:11-15): the hash-driven uniform legal pick
                                of ewn_step_out.random_action, same stream */
 #define EWN_AGENT_MINIMAX 1 /* ExpectiMinimaxAgent(agent_max_depth, 'hybrid').predict (classical_policies/minimax.py:89-93) */
+#define EWN_AGENT_SAMPLE 2  /* env.action_space.sample() on MultiDiscrete([2, 3]) (envs/ewn.py:59): uniform over all six actions, illegal ones
+                             * included -- what an untrained policy plays; hash-driven like EWN_AGENT_RANDOM, agent_max_depth ignored */
 
 typedef struct ewn_rollout_out {
     /* trajectory, row k = step k of this call; every pointer may be NULL (that column is not written) */

@@ -231,6 +231,12 @@ class OracleVecEnv:
         lib().ewn_oracle_random_actions(C.c_void_p(self.h), _p(a))
         return a
 
+    def sample_actions(self):
+        """env.action_space.sample() per lane, the hash-driven draw of ewn_step_k's EWN_AGENT_SAMPLE"""
+        a = np.zeros((self.N, 2), np.int8)
+        lib().ewn_oracle_sample_actions(C.c_void_p(self.h), _p(a))
+        return a
+
     def sample_legal_actions(self, step):
         a = np.zeros((self.N, 2), np.int8)
         lib().ewn_oracle_sample_legal_actions(C.c_void_p(self.h), C.c_uint32(step), _p(a))

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.ewn_abi_version() == 2
+    assert lib.ewn_abi_version() == 3
     assert lib.ewn_strerror(0) == b"ok" and b"invalid" in lib.ewn_strerror(-1)
 
 

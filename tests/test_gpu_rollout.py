@@ -49,6 +49,8 @@ def _rollout_vs_oracle(ea, N, lo, hi, K, launches, agent="random", agent_max_dep
         for k in range(K):
             if agent == "random":
                 acts = orc.random_actions()
+            elif agent == "sample":
+                acts = orc.sample_actions()
             else:
                 acts = po.predict_minimax(ob, od, agent_max_depth, "hybrid", cube_layer=L)[0]
             live = ~frozen
@@ -116,6 +118,18 @@ def test_rollout_slot_task_kernel_every_search(ea, kw):
     lo = 40000
     _rollout_vs_oracle(ea, SLOT_N, lo, lo + (96 if kw["max_depth"] >= 5 else 256), 7, 3, opponent_policy="minimax", rng="philox",
                        philox_key=1000 + kw["max_depth"], **kw)
+
+
+@pytest.mark.parametrize("N,lo,kw", [(1200, 0, dict(max_depth=3)), (SLOT_N, 30000, dict(max_depth=3)), (140000, 139000, dict(max_depth=2)),
+                                     (SLOT_N, 100, dict(max_depth=5)), (3000, 1000, dict(opponent="random"))],
+                         ids=lambda v: str(v) if not isinstance(v, dict) else "-".join("%s=%s" % kv for kv in sorted(v.items())))
+def test_rollout_action_space_sample_agent(ea, N, lo, kw):
+    """EWN_AGENT_SAMPLE: env.action_space.sample() as the agent -- a draw that leaves the board is an illegal move, which ends the
+    episode (envs/ewn.py:443-449) and, with auto-reset, starts the next (about one lane in ten per step): both rollout kernels."""
+    kw = dict(kw)
+    opp = kw.pop("opponent", "minimax")
+    n = _rollout_vs_oracle(ea, N, lo, lo + 200, 8, 3, agent="sample", opponent_policy=opp, rng="philox", philox_key=314, **kw)
+    assert n > 100         # episodes ended (and restarted) inside the launches
 
 
 def test_rollout_slot_task_kernel_short_launches(ea):
