@@ -190,8 +190,8 @@ class A2CTrainer:
             for p in self.model.parameters():
                 dist.broadcast(p.data, src=0)
 
-    def collect_and_update(self):
-        env, T, N = self.env, self.n_steps, self.env.N
+    def _collect(self):
+        """one n-step rollout into the preallocated buffers: eagerly the first time, as ONE hipGraph replay afterwards"""
         if self.use_graph and self._warm:
             # the whole n-step rollout (policy forward, sampling, ewn_step, bookkeeping) is one captured hipGraph: the
             # policy net is ~13 k parameters, so un-captured the loop is pure launch overhead (~25 tiny kernels per step).
@@ -207,6 +207,10 @@ class A2CTrainer:
         else:
             self._rollout()
             self._warm = True
+
+    def collect_and_update(self):
+        env, T, N = self.env, self.n_steps, self.env.N
+        self._collect()
         with torch.no_grad():
             _, _, last_value = self.model(env.board, env.dice)
         rews, dones, vals = self._rews, self._dones, self._vals

@@ -53,17 +53,7 @@ class PPOTrainer(A2CTrainer):
 
     def collect_and_update(self):
         env, T, N = self.env, self.n_steps, self.env.N
-        if self.use_graph and self._warm:
-            if self._graph is None:   # the whole n-step rollout as one captured hipGraph (see A2CTrainer.collect_and_update)
-                torch.cuda.synchronize()
-                self._graph = torch.cuda.CUDAGraph()
-                self._graph.register_generator_state(self.gen)
-                with torch.cuda.graph(self._graph):
-                    self._rollout()
-            self._graph.replay()
-        else:
-            self._rollout()
-            self._warm = True
+        self._collect()   # the n-step rollout, one hipGraph replay after the first (A2CTrainer._collect)
         boards = self._boards.reshape(T * N, env.S, env.S)
         dices, acts = self._dices.reshape(T * N), self._acts.reshape(T * N, 2)
         with torch.no_grad():
