@@ -65,6 +65,55 @@ EWN_DEV RState<S> rs_flip(const FastTab<S> *Tb, const RState<S> &s)
     return f;
 }
 
+// ---- pieces of one env step shared by the two rollout kernels below (the game is in registers, canonical ring space)
+
+// The stand-in agent's action for the current observation (the agent is the canonical BOTTOM_RIGHT side): RandomAgent.predict -- the
+// same draw ewn_step_out.random_action makes at the end of the previous step -- or, with c.agent_sample, env.action_space.sample():
+// one of the six (flag, direction) pairs, legal or not.  Hash-driven: the dice stream is not touched.
+template <int S>
+EWN_DEV void roll_stand_in_action(const FastTab<S> *Tb, const RState<S> &s, int dice, LaneRng &r, const RollCfg &c, int game, int &aflag, int &adir)
+{
+    const u32 e = pk_sel<S>(Tb, s.posN, dice), pp = pk_pair(s.posN, e);
+    const u32 okm = (u32)Tb->lgn[pp & 0xFFu] | ((u32)Tb->lgn[pp >> 8] << 3);
+    const int n = __popc(okm);
+    const u32 w = agent_hash(r.seed_mix(), r.draws(), (u32)(c.lane_offset + game), c.key);
+    if (c.agent_sample) {
+        const int a6 = (int)__umulhi(w, 6u);
+        aflag = a6 >= 3 ? 1 : 0;
+        adir = a6 - 3 * aflag;
+    } else if (n > 0) {
+        const int slot = Tb->nth[okm * 8u + __umulhi(w, (u32)n)];
+        aflag = slot < 3 ? (int)(e >> 15) : 0;
+        adir = slot < 3 ? slot : slot - 3;
+    }
+}
+
+// agent half of step() (envs/ewn.py:438-458): true if the opponent has to reply (then `dice` is the opponent's roll)
+template <int S>
+EWN_DEV bool roll_agent_half(const FastTab<S> *Tb, RState<S> &s, int aflag, int adir, int &dice, LaneRng &r, double R,
+                             double &reward, int &term, int &trunc, int &info)
+{
+    const int k = pk_cube(pk_sel<S>(Tb, s.posN, dice), aflag == 1);
+    const int q = Tb->nbn[adir][pk_get(s.posN, k)]; // no cube at all: byte 6 -> 255
+    if (q == 255) { reward = -R; term = 1; trunc = 1; info = EWN_INFO_INVALID_PLAYER; return false; }
+    rs_move<S, false>(s, k, q);
+    if (q == Tb->ri_origin || s.P == 0) { reward = R; term = 1; info = EWN_INFO_WON; return false; }
+    dice = r.randint(1, 7);
+    return true;
+}
+
+// opponent half (envs/ewn.py:464-486) once its action (oflag, odir) is known
+template <int S>
+EWN_DEV void roll_opponent_half(const FastTab<S> *Tb, RState<S> &s, u32 e, int oflag, int odir, int &dice, LaneRng &r, double R,
+                                double &reward, int &term, int &info)
+{
+    const int k = pk_cube(e, oflag == 1);
+    const int q = Tb->nbp[odir][pk_get(s.posP, k)];
+    rs_move<S, true>(s, k, q);
+    if (q == FastTab<S>::CELLS - 1 || s.N == 0) { reward = -R; term = 1; info = EWN_INFO_LOST; }
+    else dice = r.randint(1, 7);
+}
+
 // AGENT 0: RandomAgent (the hash-driven uniform legal pick of ewn_step_out.random_action); 1: ExpectiMinimaxAgent of
 // max_depth 1-4 ('hybrid'); 2: of max_depth 5-6.  OPP as in k_step_d3: 0 minimax max_depth 1-4, 1 RandomAgent, 2 minimax 5-6.
 template <int S, int T, int OPP, int RNGK, int AGENT>
@@ -131,20 +180,7 @@ __global__ __launch_bounds__(D3_BS, ((OPP == 2 || AGENT == 2) ? 2 : 1)) void k_r
         // ---- the agent's action for the current observation (the agent is the canonical BOTTOM_RIGHT side)
         int aflag = 0, adir = 0;
         if constexpr (AGENT == 0) {
-            // RandomAgent.predict: the same draw ewn_step_out.random_action makes at the end of the previous step
-            const u32 e = pk_sel<S>(Tb, s.posN, dice), pp = pk_pair(s.posN, e);
-            const u32 okm = (u32)Tb->lgn[pp & 0xFFu] | ((u32)Tb->lgn[pp >> 8] << 3);
-            const int n = __popc(okm);
-            const u32 w = agent_hash(r.seed_mix(), r.draws(), (u32)(c.lane_offset + game), c.key);
-            if (c.agent_sample) { // env.action_space.sample(): one of the six (flag, direction) pairs, legal or not
-                const int a6 = (int)__umulhi(w, 6u);
-                aflag = a6 >= 3 ? 1 : 0;
-                adir = a6 - 3 * aflag;
-            } else if (n > 0) {
-                const int slot = Tb->nth[okm * 8u + __umulhi(w, (u32)n)];
-                aflag = slot < 3 ? (int)(e >> 15) : 0;
-                adir = slot < 3 ? slot : slot - 3;
-            }
+            roll_stand_in_action<S>(Tb, s, dice, r, c, game, aflag, adir);
         } else {
             // ExpectiMinimaxAgent.predict(canonical observation): the agent's own position IS canonical for it once flipped
             const RState<S> f = rs_flip<S>(Ta, s);
@@ -158,17 +194,7 @@ __global__ __launch_bounds__(D3_BS, ((OPP == 2 || AGENT == 2) ? 2 : 1)) void k_r
         }
         RSTAMP(0); // agent's action + RNG block
         bool reply = false;
-        if (active) {
-            // agent half, envs/ewn.py:438-458
-            const int k = pk_cube(pk_sel<S>(Tb, s.posN, dice), aflag == 1);
-            const int q = Tb->nbn[adir][pk_get(s.posN, k)]; // no cube at all: byte 6 -> 255
-            if (q == 255) { reward = -c.reward; term = 1; trunc = 1; info = EWN_INFO_INVALID_PLAYER; }
-            else {
-                rs_move<S, false>(s, k, q);
-                if (q == Tb->ri_origin || s.P == 0) { reward = c.reward; term = 1; info = EWN_INFO_WON; }
-                else { dice = r.randint(1, 7); reply = true; }
-            }
-        }
+        if (active) reply = roll_agent_half<S>(Tb, s, aflag, adir, dice, r, c.reward, reward, term, trunc, info);
         RSTAMP(1); // agent half
         // the opponent's search: run by every lane (lanes without a pending reply compute on a harmless state)
         int oflag = 0, odir = 0;
@@ -185,11 +211,7 @@ __global__ __launch_bounds__(D3_BS, ((OPP == 2 || AGENT == 2) ? 2 : 1)) void k_r
                 oflag = slot < 3 ? (int)(e >> 15) : 0;
                 odir = slot < 3 ? slot : slot - 3;
             }
-            const int k = pk_cube(e, oflag == 1);
-            const int q = Tb->nbp[odir][pk_get(s.posP, k)];
-            rs_move<S, true>(s, k, q);
-            if (q == CELLS - 1 || s.N == 0) { reward = -c.reward; term = 1; info = EWN_INFO_LOST; }
-            else dice = r.randint(1, 7);
+            roll_opponent_half<S>(Tb, s, e, oflag, odir, dice, r, c.reward, reward, term, info);
         }
         if (active) {
             ret_acc += reward; n_steps++; n_eps += term; n_wins += info == EWN_INFO_WON ? 1 : 0;
@@ -328,34 +350,12 @@ __global__ __launch_bounds__(D3_BS, (OPP == 2 ? 2 : 1)) void k_rollout_slots(Rol
         const bool active = start && !frozen;
         if (start) {
             reward = 0.0; term = frozen ? 1 : 0; trunc = 0; info = EWN_INFO_NONE; reply = false; aflag = 0; adir = 0;
-            // RandomAgent.predict for the current observation (the agent is the canonical BOTTOM_RIGHT side): the same draw
-            // ewn_step_out.random_action makes at the end of the previous step
-            const u32 e = pk_sel<S>(Tb, s.posN, dice), pp = pk_pair(s.posN, e);
-            const u32 okm = (u32)Tb->lgn[pp & 0xFFu] | ((u32)Tb->lgn[pp >> 8] << 3);
-            const int n = __popc(okm);
-            const u32 w = agent_hash(r.seed_mix(), r.draws(), (u32)(c.lane_offset + game), c.key);
-            if (c.agent_sample) { // env.action_space.sample(): one of the six (flag, direction) pairs, legal or not
-                const int a6 = (int)__umulhi(w, 6u);
-                aflag = a6 >= 3 ? 1 : 0;
-                adir = a6 - 3 * aflag;
-            } else if (n > 0) {
-                const int sl = Tb->nth[okm * 8u + __umulhi(w, (u32)n)];
-                aflag = sl < 3 ? (int)(e >> 15) : 0;
-                adir = sl < 3 ? sl : sl - 3;
-            }
+            roll_stand_in_action<S>(Tb, s, dice, r, c, game, aflag, adir);
             if (active) { // a frozen lane's stream stays where its last step left it
                 if constexpr (RNGK == 0) r.prefetch();
                 r.begin_step();
                 if constexpr (RNGK == 1) r.ps.prime();
-                // agent half, envs/ewn.py:438-458
-                const int k = pk_cube(e, aflag == 1);
-                const int q = Tb->nbn[adir][pk_get(s.posN, k)]; // no cube at all: byte 6 -> 255
-                if (q == 255) { reward = -c.reward; term = 1; trunc = 1; info = EWN_INFO_INVALID_PLAYER; }
-                else {
-                    rs_move<S, false>(s, k, q);
-                    if (q == Tb->ri_origin || s.P == 0) { reward = c.reward; term = 1; info = EWN_INFO_WON; }
-                    else { dice = r.randint(1, 7); reply = true; }
-                }
+                reply = roll_agent_half<S>(Tb, s, aflag, adir, dice, r, c.reward, reward, term, trunc, info);
             }
         }
         // one cube's three roots of the opponent's search, run by every lane (lanes without a pending reply compute on a harmless
@@ -366,15 +366,7 @@ __global__ __launch_bounds__(D3_BS, (OPP == 2 ? 2 : 1)) void k_rollout_slots(Rol
         if (pending && phase == 0 && reply && second) phase = 1; // the same env step goes on with the second cube
         else if (pending) {
             phase = 0;
-            if (reply) {
-                // opponent half, envs/ewn.py:464-486
-                const u32 e = pk_sel<S>(Tb, s.posP, dice);
-                const int k = pk_cube(e, oflag == 1);
-                const int q = Tb->nbp[odir][pk_get(s.posP, k)];
-                rs_move<S, true>(s, k, q);
-                if (q == CELLS - 1 || s.N == 0) { reward = -c.reward; term = 1; info = EWN_INFO_LOST; }
-                else dice = r.randint(1, 7);
-            }
+            if (reply) roll_opponent_half<S>(Tb, s, pk_sel<S>(Tb, s.posP, dice), oflag, odir, dice, r, c.reward, reward, term, info);
             if (!frozen) {
                 ret_acc += reward; n_steps++; n_eps += term; n_wins += info == EWN_INFO_WON ? 1 : 0;
                 if (term) {
