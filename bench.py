@@ -66,9 +66,9 @@ def parse():
     ap.add_argument("--graph-steps", type=int, default=50, help="env steps captured per graph (step mode)")
     ap.add_argument("--mt-window", type=int, default=0, help="MT19937-compat mode: precomputed outputs per episode window (0 = engine default)")
     ap.add_argument("--no-spin", action="store_true", help="skip the clock warm-up on a scratch env before the timed region")
-    ap.add_argument("--spin-ms", type=float, default=250.0,
-                    help="approximate length of that clock warm-up (6 ms already removes the 4 %% penalty; two main measurements out of ~100 "
-                         "still started 3x slow after seconds of GPU idleness, later measurements of the same process never did)")
+    ap.add_argument("--spin-ms", type=float, default=6.0,
+                    help="approximate length of that clock warm-up (measured on the driver's 20-step shape, five runs each: 6 ms 6.06-6.18 G steps/s, "
+                         "30 ms 5.3-6.1, 100 ms 5.6-6.0, 250 ms 2.9-5.5 -- after a long eager queue the single graph launch starts late)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra measurements (single-step launch, no-trajectory rollout, uniform6 agent)")
     return ap.parse_args()
 
