@@ -54,6 +54,9 @@ def parse():
                     help="rollout: ewn_step_k, --steps-per-launch env steps per kernel launch; step: one ewn_step launch per env step; "
                          "auto: rollout where the engine has it for the configuration, else step")
     ap.add_argument("--steps-per-launch", type=int, default=50, help="rollout mode: env steps per ewn_step_k launch")
+    ap.add_argument("--trajectory-layout", default="record", choices=["record", "columns"],
+                    help="rollout mode: record = one 16-byte aligned record per lane-step (board | dice | action | flags; 32 B for 5x5) + the f64 "
+                         "reward column; columns = packed [K][N][S*S] boards + one array per field (round 2's layout)")
     ap.add_argument("--no-trajectory", action="store_true",
                     help="rollout mode: do not write the per-step trajectory (only final state and per-lane counters)")
     ap.add_argument("--agent", default="legal", choices=["legal", "uniform6"],
@@ -137,10 +140,12 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_key(mode, opponent, max_depth, rng, board_size, lanes, steps_per_launch, trajectory):
+def pmc_key(mode, opponent, max_depth, rng, board_size, lanes, steps_per_launch, trajectory, layout="record"):
     key = "%s_%s_d%d_%s_%dx%d_%d" % (mode, opponent, max_depth, rng, board_size, board_size, lanes)
     if mode == "rollout":
         key += "_k%d%s" % (steps_per_launch, "" if trajectory else "_notraj")
+        if trajectory and layout != "record":
+            key += "_" + layout
     return key
 
 
@@ -199,7 +204,7 @@ class Runner:
         self.trajectory = trajectory
         if mode == "rollout":
             self.K = max(1, min(args.steps_per_launch, args.steps))
-            self.traj = env.alloc_rollout(self.K) if trajectory else None
+            self.traj = env.alloc_rollout(self.K, layout=args.trajectory_layout) if trajectory else None
             self.kernels_per_step = 1.0 / self.K
         else:
             self.K = 1
@@ -426,7 +431,7 @@ def main():
         if os.path.exists(tpath):
             try:   # PMC results of this kernel at this size, collected by tools/pmc_passes.sh in separate rocprofv3 passes
                 pmc = json.load(open(tpath))
-                ent = pmc.get(pmc_key(mode, args.opponent, args.max_depth, args.rng, args.board_size, N, runner.K, runner.trajectory))
+                ent = pmc.get(pmc_key(mode, args.opponent, args.max_depth, args.rng, args.board_size, N, runner.K, runner.trajectory, args.trajectory_layout))
                 if ent and pmc.get("source_hash") == source_hash():
                     traffic = ent["hbm_bytes_per_launch"]
                     rocprof_ms = ent.get("rocprof_avg_us", 0.0) / 1e3 or None
@@ -449,7 +454,9 @@ def main():
                         "kernel at this launch shape (profiles/pmc_traffic.json, same kernel sources)" + note}
         if mode == "rollout":
             launch = "ewn_step_k: %d env steps per launch, %s; %s" % (
-                runner.K, "per-step trajectory (obs, action, reward, flags) written to HBM" if runner.trajectory else "no trajectory output",
+                runner.K, ("per-step trajectory (obs, action, reward, flags) written to HBM, %s" %
+                           ("one aligned %d-byte record per lane-step + f64 reward" % ((args.board_size ** 2 + 6 + 15) & ~15) if args.trajectory_layout == "record"
+                            else "packed columns")) if runner.trajectory else "no trajectory output",
                 runner.graph_kind + " replay" if not args.no_graph else "eager")
         else:
             launch = "one ewn_step launch per env step; " + ("hipGraph replay (%s)" % ", ".join("%d x %d steps" % (r, g) for g, r in runner.plan(args.steps))

@@ -134,7 +134,9 @@ class EinsteinWuerfeltNichtEnv(_Base):
         return self._obs(), reward, bool(terminated), bool(truncated), ({"message": msg} if msg else {})
 
     def roll_dice(self):
-        raise NotImplementedError("dice are rolled on the device inside reset()/step()")
+        """envs/ewn.py:90-92: dice_roll = np.random.randint(1, cube_num + 1) -- drawn on the device from this env's own dice
+        stream (the numpy-compatible MT19937 kind: the same value upstream's next global draw gives a freshly seeded env)."""
+        self.dice_roll = int(self._engine.roll_dice().cpu()[0])
 
     def switch_player(self):
         self.current_player = Player.get_opponent(self.current_player)

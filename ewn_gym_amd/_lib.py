@@ -23,7 +23,7 @@ INFO_MESSAGES = {
 EXPORTS = ["ewn_abi_version", "ewn_strerror", "ewn_rng_words", "ewn_step_scratch_bytes", "ewn_tables_bytes",
            "ewn_build_tables", "ewn_init_aux", "ewn_reset",
            "ewn_step", "ewn_legal_actions", "ewn_apply_action", "ewn_playout_wins", "ewn_evaluate", "ewn_predict_minimax", "ewn_predict_random",
-           "ewn_predict_mcts", "ewn_step_k", "ewn_step_k_supported", "ewn_predict_minimax_sim", "ewn_lanes_per_game"]
+           "ewn_predict_mcts", "ewn_step_k", "ewn_step_k_supported", "ewn_predict_minimax_sim", "ewn_lanes_per_game", "ewn_roll_dice"]
 AGENT = {"random": 0, "minimax": 1, "sample": 2}   # "sample": env.action_space.sample(), all six actions (EWN_AGENT_SAMPLE)
 
 
@@ -53,7 +53,8 @@ class EwnStepOut(C.Structure):  # struct ewn_step_out
 class EwnRolloutOut(C.Structure):  # struct ewn_rollout_out
     _fields_ = [("board", C.c_void_p), ("dice", C.c_void_p), ("action", C.c_void_p), ("reward", C.c_void_p),
                 ("terminated", C.c_void_p), ("truncated", C.c_void_p), ("info", C.c_void_p),
-                ("return_sum", C.c_void_p), ("n_steps", C.c_void_p), ("n_episodes", C.c_void_p), ("n_wins", C.c_void_p)]
+                ("return_sum", C.c_void_p), ("n_steps", C.c_void_p), ("n_episodes", C.c_void_p), ("n_wins", C.c_void_p),
+                ("record", C.c_void_p)]
 
 
 class EwnError(RuntimeError):
@@ -92,6 +93,7 @@ def load():
         "ewn_build_tables": (i32, [i32, i32, vp]),
         "ewn_init_aux": (i32, [cfgp, stp, vp]),
         "ewn_reset": (i32, [cfgp, stp, vp, vp, vp]),
+        "ewn_roll_dice": (i32, [cfgp, stp, vp, vp]),
         "ewn_step": (i32, [cfgp, stp, vp, outp, vp, vp]),
         "ewn_legal_actions": (i32, [i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
         "ewn_apply_action": (i32, [i32, i32, i32, vp, vp, i32, vp, vp, vp, vp]),
@@ -108,7 +110,7 @@ def load():
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.ewn_abi_version() != 3:
+    if lib.ewn_abi_version() != 4:
         raise EwnError("libewn_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -245,11 +245,24 @@ class A2CTrainer:
         """A batched policy for tournament.evaluate / hand-rolled loops: (board, dice, t) -> int8 [N,2]"""
         return lambda b, d, t: self.model.act(b, d, deterministic=deterministic, generator=self.gen)[0]
 
+    algorithm = "A2C"
+    best_score = -1.0     # best evaluation win rate seen so far (train.py:109-112); travels with the checkpoint
+
     def save(self, path):
-        torch.save({"model": self.model.state_dict(), "opt": self.opt.state_dict(), "num_timesteps": self.num_timesteps}, path)
+        torch.save({"algorithm": self.algorithm, "model": self.model.state_dict(), "opt": self.opt.state_dict(),
+                    "num_timesteps": self.num_timesteps, "best_score": float(self.best_score),
+                    "generator": self.gen.get_state().cpu()}, path)
 
     def load(self, path):
         sd = torch.load(path, map_location=self.device, weights_only=True)
+        algo = sd.get("algorithm", "A2C")
+        if algo != self.algorithm:   # an RMSprop state dict in PPO's Adam (or the reverse) would mis-load or fail obscurely
+            raise ValueError("checkpoint %s was written by the %s trainer, this is the %s trainer" % (path, algo, self.algorithm))
         self.model.load_state_dict(sd["model"])
         self.opt.load_state_dict(sd["opt"])
         self.num_timesteps = sd["num_timesteps"]
+        self.best_score = float(sd.get("best_score", -1.0))
+        if "generator" in sd:        # the sampling noise continues where the saved run stopped
+            self.gen.set_state(sd["generator"].cpu())
+        self._graph = None           # a captured rollout holds the old generator registration
+        self._warm = False

@@ -179,6 +179,18 @@ __global__ __launch_bounds__(BS) void k_init_aux(Geom g, KCfg c, KState st, int 
     if (st.tolerance) st.tolerance[lane] = tol0;
 }
 
+// roll_dice (envs/ewn.py:90-92): dice_roll = np.random.randint(1, cube_num + 1) on the lane's own stream -- the one draw, nothing else
+// of the game changes.  A lane whose game is finished and not yet reset keeps its (stale) dice, as the terminal observation does upstream.
+__global__ __launch_bounds__(BS) void k_roll_dice(Geom g, KCfg c, KState st, const uint8_t *mask)
+{
+    const int lane = blockIdx.x * BS + threadIdx.x;
+    if (lane >= c.N || (mask && !mask[lane]) || st.done[lane]) return;
+    const uint4 hdr = *rng_hdr_ptr(st.rng, lane);
+    LaneRng r; r.load(c.rng_kind, hdr, rng_win_ptr(st.rng, c.N, c.W, lane, RNGF_CUR(hdr.w)), c.W, c.key);
+    st.dice[lane] = (int8_t)r.randint(1, g.CN + 1);
+    *rng_hdr_ptr(st.rng, lane) = r.header();
+}
+
 // ---------------------------------------------------------------- step kernels
 
 // PHASE 0: fused (agent + in-thread opponent policy + finish)
@@ -543,8 +555,11 @@ EWN_DEV void rollout_ply(const Geom &g, GState<NW> &s, PlayoutRng &ps)
 // (evaluate() returns simulate() before that test, :37-38: a finished position scores 1.0 or 0.0), and the side to move in a
 // playout is `current_player` of the policy's private env, which simulate() flips before EVERY move and never restores: the
 // first mover of a playout is whoever did not make the last move of the previous one, across leaves too.  The search never sets
-// current_player, so that chain is all there is; it starts at TOP_LEFT (the env right after construction).  One generator per
-// search, drawn from in the order of the depth-first search.  Statistical parity with the reference (unseeded Python
+// current_player, so that chain is all there is.  DELIBERATE DEVIATION: here the chain starts at TOP_LEFT (the env right after
+// construction) at EVERY predict(); upstream the agent's private env persists, so from its second predict() on the first mover of
+// the first playout is inherited from the previous call.  A stateless batched policy has no "previous call" (observations of many
+// games arrive in one batch, in any order); the effect is on which side moves first in a random playout, statistical only, and the
+// reference pins nothing here (unseeded `random`).  One generator per search, drawn from in the order of the depth-first search.  Statistical parity with the reference (unseeded Python
 // `random`); bit-exact with oracle/ewn_oracle.c, which mirrors it.
 template <int NW>
 struct SimLeaf {
@@ -822,6 +837,16 @@ int ewn_reset(const ewn_config *cfg, const ewn_state *st, const uint32_t *seeds,
     return launch_status();
 }
 
+int ewn_roll_dice(const ewn_config *cfg, const ewn_state *st, const uint8_t *lane_mask, void *stream)
+{
+    Geom g; KCfg k;
+    int rc = check_cfg(cfg, g, k);
+    if (rc) return rc;
+    if (!st || !st->dice || !st->done || !st->rng) return EWN_ENULL;
+    k_roll_dice<<<GRID(k.N), BS, 0, (hipStream_t)stream>>>(g, k, kstate(st), lane_mask);
+    return launch_status();
+}
+
 int ewn_predict_mcts(int board_size, int cube_layer, int M, const int8_t *boards, const int8_t *dice, int num_simulations,
                      int num_env_copies, uint64_t key, const uint32_t *obs_id, int8_t *actions, int32_t *wins, void *stream);
 
@@ -991,6 +1016,7 @@ int ewn_step_k(const ewn_config *cfg, const ewn_state *st, int K, int agent_kind
         rb.t_board = out->board; rb.t_dice = out->dice; rb.t_action = out->action; rb.t_reward = out->reward;
         rb.t_term = out->terminated; rb.t_trunc = out->truncated; rb.t_info = out->info;
         rb.ret_sum = out->return_sum; rb.n_steps = out->n_steps; rb.n_episodes = out->n_episodes; rb.n_wins = out->n_wins;
+        rb.t_rec = out->record;
     }
     hipStream_t s = (hipStream_t)stream;
     switch (g.S) {

@@ -39,6 +39,7 @@ struct RollBuf {
     const void *agent_tables;  // table image of the agent's search; == tables when both use the same image (or the agent is random)
     // trajectory [K][N]..., each may be NULL
     int8_t *t_board; int8_t *t_dice; int8_t *t_action; double *t_reward; uint8_t *t_term; uint8_t *t_trunc; uint8_t *t_info;
+    uint8_t *t_rec;            // [K][N][EWN_TRAJ_RECORD_STRIDE(S)] one aligned record per lane-step (ewn_rollout_out.record), or NULL
     // per-lane accumulators, each may be NULL
     double *ret_sum; int32_t *n_steps; int32_t *n_episodes; int32_t *n_wins;
 };
@@ -65,6 +66,83 @@ EWN_DEV RState<S> rs_flip(const FastTab<S> *Tb, const RState<S> &s)
     return f;
 }
 
+// ---- the trajectory as ONE aligned record per lane-step (ewn_rollout_out.record): the S*S board bytes, then dice, action[2],
+// terminated, truncated, info, zero padding up to a multiple of 16 bytes (32 for 5x5, 64 for 7x7).  A game's row is then one or
+// two whole 32-byte sectors written with 16-byte stores, wherever its neighbours are in their own step count (the slot-task
+// kernel's games drift apart): measured round 2, the packed [K][N][S*S] board column of drifted games cost 47-69 written bytes
+// per lane-step for 39 algorithmic.  The board bytes come from a per-game LDS slot that is kept CURRENT move by move (two byte
+// stores per move) instead of being re-encoded from the position registers every step.
+template <int S> struct RecGeo {
+    static constexpr int CELLS = S * S, STR = (CELLS + 6 + 15) & ~15, NCH = STR / 16;
+    static_assert(STR == EWN_TRAJ_RECORD_STRIDE(S), "include/ewn_hip.h states the stride");
+};
+
+// the start position (envs/ewn.py:94-107) as record bytes (meta and padding zero), little-endian words
+template <int S> struct InitRec {
+    u32 w[RecGeo<S>::STR / 4];
+    constexpr InitRec() : w()
+    {
+        int b[RecGeo<S>::STR] = {};
+        int cnt = 1;
+        for (int i = 1; i <= 3; i++)
+            for (int j = 0; j < i; j++) { b[j * S + (i - j - 1)] = cnt; b[(S - 1 - j) * S + (S - i + j)] = -cnt; cnt++; }
+        for (int i = 0; i < RecGeo<S>::STR; i++) w[i / 4] |= (u32)(b[i] & 0xFF) << (8 * (i % 4));
+    }
+};
+
+// (re)build a game's slot from the position registers: launch start only
+template <int S, int T>
+EWN_DEV void rec_slot_build(const FastTab<S> *Tb, const RState<S> &s, int sub, int8_t *slot)
+{
+    #pragma unroll
+    for (int c0 = 0; c0 < RecGeo<S>::NCH; c0 += T) { const int c = c0 + sub; if (c < RecGeo<S>::NCH) ((uint4 *)slot)[c] = make_uint4(0u, 0u, 0u, 0u); }
+    __builtin_amdgcn_wave_barrier();   // the zeroing of every lane of the game is issued before any cube byte
+    d3_encode_cubes<S, T>(Tb, s, sub, slot);
+    __builtin_amdgcn_wave_barrier();
+}
+
+// setup_game into the slot (auto-reset): every lane of the game stores the same constants
+template <int S>
+EWN_DEV void rec_slot_init(int8_t *slot)
+{
+    constexpr InitRec<S> I{};
+    #pragma unroll
+    for (int c = 0; c < RecGeo<S>::NCH; c++) ((uint4 *)slot)[c] = make_uint4(I.w[4 * c], I.w[4 * c + 1], I.w[4 * c + 2], I.w[4 * c + 3]);
+}
+
+// one record out: lane `sub` of the game's T lanes takes the 16-byte pieces sub, sub + T, ...; the six meta bytes are OR-ed into
+// the piece(s) they fall in on the way (their slot bytes stay zero)
+template <int S, int T>
+EWN_DEV void rec_store(const int8_t *slot, int sub, int dice, int aflag, int adir, int term, int trunc, int info, uint8_t *dst)
+{
+    constexpr int CELLS = RecGeo<S>::CELLS, NCH = RecGeo<S>::NCH;
+    const u32 meta[6] = { (u32)dice & 0xFFu, (u32)aflag & 0xFFu, (u32)adir & 0xFFu, (u32)term, (u32)trunc, (u32)info };
+    #pragma unroll
+    for (int c0 = 0; c0 < NCH; c0 += T) {
+        const int c = c0 + sub;
+        if (c < NCH) {
+            const uint4 v = ((const uint4 *)slot)[c];
+            u32 w[4] = { v.x, v.y, v.z, v.w };
+            #pragma unroll
+            for (int cc = c0; cc < c0 + T && cc < NCH; cc++) { // the compile-time candidates for c
+                u32 add[4] = { 0u, 0u, 0u, 0u };
+                bool any = false;
+                #pragma unroll
+                for (int m = 0; m < 6; m++) {
+                    const int off = CELLS + m;
+                    if (off / 16 == cc) { add[(off % 16) / 4] |= meta[m] << (8 * (off % 4)); any = true; }
+                }
+                if (any) {
+                    const bool me = T == 1 || c == cc;
+                    #pragma unroll
+                    for (int i = 0; i < 4; i++) w[i] |= me ? add[i] : 0u;
+                }
+            }
+            *(uint4 *)(dst + 16 * c) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+}
+
 // ---- pieces of one env step shared by the two rollout kernels below (the game is in registers, canonical ring space)
 
 // The stand-in agent's action for the current observation (the agent is the canonical BOTTOM_RIGHT side): RandomAgent.predict -- the
@@ -89,13 +167,19 @@ EWN_DEV void roll_stand_in_action(const FastTab<S> *Tb, const RState<S> &s, int 
 }
 
 // agent half of step() (envs/ewn.py:438-458): true if the opponent has to reply (then `dice` is the opponent's roll)
+// slot: the game's board bytes in LDS, kept current (NULL: the caller encodes the board itself)
 template <int S>
 EWN_DEV bool roll_agent_half(const FastTab<S> *Tb, RState<S> &s, int aflag, int adir, int &dice, LaneRng &r, double R,
-                             double &reward, int &term, int &trunc, int &info)
+                             double &reward, int &term, int &trunc, int &info, int8_t *slot = nullptr)
 {
     const int k = pk_cube(pk_sel<S>(Tb, s.posN, dice), aflag == 1);
-    const int q = Tb->nbn[adir][pk_get(s.posN, k)]; // no cube at all: byte 6 -> 255
+    const int pb = pk_get(s.posN, k);
+    const int q = Tb->nbn[adir][pb]; // no cube at all: byte 6 -> 255
     if (q == 255) { reward = -R; term = 1; trunc = 1; info = EWN_INFO_INVALID_PLAYER; return false; }
+    if (slot) { // the agent's cube k is the real +(k + 1); source first: LDS stores of one wave land in program order
+        const int cp = Tb->real_of_ring[pb & 63], cq = Tb->real_of_ring[q];
+        slot[cp] = 0; slot[cq] = (int8_t)(k + 1);
+    }
     rs_move<S, false>(s, k, q);
     if (q == Tb->ri_origin || s.P == 0) { reward = R; term = 1; info = EWN_INFO_WON; return false; }
     dice = r.randint(1, 7);
@@ -105,10 +189,12 @@ EWN_DEV bool roll_agent_half(const FastTab<S> *Tb, RState<S> &s, int aflag, int 
 // opponent half (envs/ewn.py:464-486) once its action (oflag, odir) is known
 template <int S>
 EWN_DEV void roll_opponent_half(const FastTab<S> *Tb, RState<S> &s, u32 e, int oflag, int odir, int &dice, LaneRng &r, double R,
-                                double &reward, int &term, int &info)
+                                double &reward, int &term, int &info, int8_t *slot = nullptr)
 {
     const int k = pk_cube(e, oflag == 1);
-    const int q = Tb->nbp[odir][pk_get(s.posP, k)];
+    const int pb = pk_get(s.posP, k);
+    const int q = Tb->nbp[odir][pb];
+    if (slot) { const int cp = Tb->real_of_ring[pb & 63], cq = Tb->real_of_ring[q & 63]; slot[cp] = 0; slot[cq] = (int8_t)(-(k + 1)); }
     rs_move<S, true>(s, k, q);
     if (q == FastTab<S>::CELLS - 1 || s.N == 0) { reward = -R; term = 1; info = EWN_INFO_LOST; }
     else dice = r.randint(1, 7);
@@ -126,7 +212,7 @@ __global__ __launch_bounds__(D3_BS, ((OPP == 2 || AGENT == 2) ? 2 : 1)) void k_r
     // dynamic-LDS base is a link-time symbol the compiler adds with one VALU instruction in front of every table read (43 per
     // root of the search).  Two images (minimax agents of another depth class) can exceed the 64 KB static limit: dynamic.
     extern __shared__ __attribute__((aligned(16))) int8_t lds_dyn[];
-    constexpr int LDS_STATIC = AGENT == 0 ? ((GPB * CELLS + 15) & ~15) + FAST_TAB_BYTES(S) + GPB * 16 : 16;
+    constexpr int LDS_STATIC = AGENT == 0 ? ((GPB * CELLS + 15) & ~15) + FAST_TAB_BYTES(S) + GPB * 16 + GPB * RecGeo<S>::STR : 16;
     __shared__ __attribute__((aligned(16))) int8_t lds_st[LDS_STATIC];
     int8_t *lds = AGENT == 0 ? lds_st : lds_dyn;
     int8_t *tb = lds + ((GPB * CELLS + 15) & ~15);
@@ -140,6 +226,7 @@ __global__ __launch_bounds__(D3_BS, ((OPP == 2 || AGENT == 2) ? 2 : 1)) void k_r
         after += FAST_TAB_BYTES(S);
     }
     uint8_t *garr = (uint8_t *)after;             // 16 bytes per game: d3_decode's scatter area
+    int8_t *rec_slot = (int8_t *)garr + GPB * 16 + ((int)threadIdx.x / T) * RecGeo<S>::STR; // the game's record staging slot (B.t_rec)
 
     const int g0 = (int)blockIdx.x * GPB, ng = min(GPB, c.N - g0);
     const int gl = threadIdx.x / T, sub = threadIdx.x % T, game = g0 + gl;
@@ -234,6 +321,11 @@ __global__ __launch_bounds__(D3_BS, ((OPP == 2 || AGENT == 2) ? 2 : 1)) void k_r
             if (B.t_trunc) B.t_trunc[o] = (uint8_t)trunc;
             if (B.t_info) B.t_info[o] = (uint8_t)info;
         }
+        if (B.t_rec) { // one aligned record per lane-step (ewn_rollout_out.record), the board re-encoded into the game's slot
+            rec_slot_build<S, T>(Tb, s, sub, rec_slot);
+            if (live) rec_store<S, T>(rec_slot, sub, dice, aflag, adir, term, trunc, info, B.t_rec + ((size_t)kstep * c.N + game) * RecGeo<S>::STR);
+            __builtin_amdgcn_wave_barrier();
+        }
         if (want_board) {
             // A wave's games are one contiguous, 16-byte aligned span of LDS (64 / T games x S*S bytes): the wave copies its own
             // span out and no block-wide barrier is needed, so the waves of a block drift apart freely (LDS operations of one
@@ -305,7 +397,7 @@ __global__ __launch_bounds__(D3_BS, (OPP == 2 ? 2 : 1)) void k_rollout_slots(Rol
     static_assert(OPP == 0 || OPP == 2, "minimax opponents");
     constexpr int CELLS = S * S, GPB = D3_BS / T;   // games per block
     constexpr int TS = T > 2 ? 2 : T;               // lanes per game the depth-5 search can use
-    constexpr int STR = (CELLS + 15) & ~15;         // LDS bytes per game: a 16-byte aligned staging slot for the board
+    constexpr int STR = RecGeo<S>::STR;             // LDS bytes per game: the game's board slot, one trajectory record wide
     __shared__ __attribute__((aligned(16))) int8_t lds_st[GPB * STR + FAST_TAB_BYTES(S) + GPB * 16];
     int8_t *lds = lds_st;
     int8_t *tb = lds + GPB * STR;
@@ -334,8 +426,11 @@ __global__ __launch_bounds__(D3_BS, (OPP == 2 ? 2 : 1)) void k_rollout_slots(Rol
     __syncthreads();
     RState<S> s;
     d3_decode<S, T>(live ? lds + gl * CELLS : lds, sub, garr + gl * 16, s);
-    __syncthreads();                                // every game is in registers: the board area becomes the staging slots
+    __syncthreads();                                // every game is in registers: the board area becomes the per-game slots
     int8_t *slot_b = lds + gl * STR;
+    const bool want_slot = B.t_board != nullptr || B.t_rec != nullptr;
+    int8_t *slot_m = want_slot ? slot_b : nullptr;  // kept current by the two halves of a step and by the auto-reset
+    if (want_slot) rec_slot_build<S, T>(Tb, s, sub, slot_b);
     double ret_acc = 0.0;
     int n_steps = 0, n_eps = 0, n_wins = 0;
 
@@ -355,7 +450,7 @@ __global__ __launch_bounds__(D3_BS, (OPP == 2 ? 2 : 1)) void k_rollout_slots(Rol
                 if constexpr (RNGK == 0) r.prefetch();
                 r.begin_step();
                 if constexpr (RNGK == 1) r.ps.prime();
-                reply = roll_agent_half<S>(Tb, s, aflag, adir, dice, r, c.reward, reward, term, trunc, info);
+                reply = roll_agent_half<S>(Tb, s, aflag, adir, dice, r, c.reward, reward, term, trunc, info, slot_m);
             }
         }
         // one cube's three roots of the opponent's search, run by every lane (lanes without a pending reply compute on a harmless
@@ -366,13 +461,14 @@ __global__ __launch_bounds__(D3_BS, (OPP == 2 ? 2 : 1)) void k_rollout_slots(Rol
         if (pending && phase == 0 && reply && second) phase = 1; // the same env step goes on with the second cube
         else if (pending) {
             phase = 0;
-            if (reply) roll_opponent_half<S>(Tb, s, pk_sel<S>(Tb, s.posP, dice), oflag, odir, dice, r, c.reward, reward, term, info);
+            if (reply) roll_opponent_half<S>(Tb, s, pk_sel<S>(Tb, s.posP, dice), oflag, odir, dice, r, c.reward, reward, term, info, slot_m);
             if (!frozen) {
                 ret_acc += reward; n_steps++; n_eps += term; n_wins += info == EWN_INFO_WON ? 1 : 0;
                 if (term) {
                     if (c.autoreset) { // reset(seed = next_seed) + setup_game (envs/ewn.py:488-494, 94-108); Philox kind only (host check)
                         r.next_episode(B.rng, c.N, game, c.seed_stride, c.key, nullptr);
                         d3_init_state<S>(Tb, s);
+                        if (want_slot) rec_slot_init<S>(slot_b);
                         dice = r.first_dice(6);
                     } else frozen = true;
                 }
@@ -387,12 +483,11 @@ __global__ __launch_bounds__(D3_BS, (OPP == 2 ? 2 : 1)) void k_rollout_slots(Rol
                 if (B.t_trunc) B.t_trunc[o] = (uint8_t)trunc;
                 if (B.t_info) B.t_info[o] = (uint8_t)info;
             }
+            if (want_slot) __builtin_amdgcn_wave_barrier(); // this step's byte stores of every lane of the game are issued before its slot is read
+            if (B.t_rec) rec_store<S, T>(slot_b, sub, dice, aflag, adir, term, trunc, info, B.t_rec + o * STR);
             if (B.t_board) {
-                // the game's board through its own 16-byte aligned LDS slot: zero it, drop the cube bytes in, copy it out (LDS
-                // operations of one wave execute in program order; the T lanes of a game are in one wave)
-                #pragma unroll
-                for (int i = sub; i < STR / 16; i += T) ((uint4 *)slot_b)[i] = make_uint4(0u, 0u, 0u, 0u);
-                d3_encode_cubes<S, T>(Tb, s, sub, slot_b);
+                // the game's board out of its LDS slot (LDS operations of one wave execute in program order; the T lanes of a game
+                // are in one wave)
                 // copy out: each of the T lanes a contiguous run of whole dwords, the last lane the odd tail.  The row sits at a
                 // byte offset of o * CELLS: an UNALIGNED destination, which global memory accepts (the compiler knows: a 4-byte
                 // memcpy to a char pointer becomes one dword store on this target); a quarter of the requests of a byte copy

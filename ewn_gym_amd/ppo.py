@@ -23,6 +23,8 @@ from .a2c import A2CTrainer, all_reduce_gradients, n_step_returns
 
 
 class PPOTrainer(A2CTrainer):
+    algorithm = "PPO"
+
     def __init__(self, env, n_steps=32, batch_size=None, n_epochs=10, learning_rate=3e-4, gamma=0.99, gae_lambda=0.95,
                  clip_range=0.2, normalize_advantage=True, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, seed=None,
                  hidden=64, device=None, use_graph=True):

@@ -69,7 +69,7 @@ def main():
         trainer.load(a.checkpoint)
         if rank == 0:
             print(json.dumps({"resumed_from": a.checkpoint, "timesteps": trainer.num_timesteps * world}), flush=True)
-    best = -1.0
+    best = trainer.best_score   # -1 for a fresh run; a resumed one keeps its best model until it is beaten
     for epoch in range(a.epoch_num):
         stats = trainer.learn(a.timesteps_per_epoch // world)   # dict of the last update's statistics
         # train.py:73-81: evaluate on the UN-shaped env against minimax(depth 5), seeds 0..n-1, deterministic actions
@@ -81,7 +81,7 @@ def main():
         if rank == 0:
             print(json.dumps({"epoch": epoch, "timesteps": trainer.num_timesteps * world, "win_rate": win_rate, **stats}), flush=True)
             if win_rate > best:          # train.py:109-112
-                best = win_rate
+                best = trainer.best_score = win_rate
                 os.makedirs(a.save_dir, exist_ok=True)
                 trainer.save(os.path.join(a.save_dir, "best.pt"))
     if world > 1:

@@ -107,6 +107,14 @@ class VecEWN:
         check(self.lib.ewn_reset(C.byref(self.cfg), C.byref(self._st), _ptr(seeds), _ptr(mask), _stream()), "ewn_reset")
         return self.board, self.dice
 
+    # -- roll_dice() (envs/ewn.py:90-92): one draw from each selected lane's dice stream
+    def roll_dice(self, mask=None):
+        if mask is not None:
+            mask = torch.as_tensor(mask).to(self.device).to(torch.uint8).contiguous()
+            assert mask.numel() == self.N
+        check(self.lib.ewn_roll_dice(C.byref(self.cfg), C.byref(self._st), _ptr(mask), _stream()), "ewn_roll_dice")
+        return self.dice
+
     # -- step(actions) (envs/ewn.py:436-486 / envs/training_ewn.py:43-99)
     def step(self, actions):
         if not (isinstance(actions, torch.Tensor) and actions.dtype == torch.int8 and actions.is_cuda and actions.is_contiguous()):
@@ -148,9 +156,21 @@ class VecEWN:
             return False
         return self.lib.ewn_step_k_supported(C.byref(self.cfg), AGENT[agent], int(agent_max_depth)) == 1
 
-    def alloc_rollout(self, K, board=True):
-        """Trajectory buffers for rollout(K, traj=...): dict of [K, N, ...] tensors (the observation column is optional)"""
+    def alloc_rollout(self, K, board=True, layout="columns"):
+        """Trajectory buffers for rollout(K, traj=...): dict of [K, N, ...] tensors (the observation column is optional).
+        layout="record": ONE 16-byte aligned record per lane-step (ewn_rollout_out.record: board | dice | action | terminated |
+        truncated | info | padding; 32 bytes for 5x5) plus the f64 reward column; the dict's board / dice / action / flag entries
+        are then strided VIEWS into the records."""
         dev, N, S = self.device, self.N, self.S
+        if layout == "record":
+            C2 = S * S
+            stride = (C2 + 6 + 15) & ~15
+            rec = torch.zeros((K, N, stride), dtype=torch.uint8, device=dev)
+            return {"record": rec, "reward": torch.zeros((K, N), dtype=torch.float64, device=dev),
+                    "board": rec[:, :, :C2].view(torch.int8).unflatten(2, (S, S)), "dice": rec[:, :, C2].view(torch.int8),
+                    "action": rec[:, :, C2 + 1:C2 + 3].view(torch.int8), "terminated": rec[:, :, C2 + 3],
+                    "truncated": rec[:, :, C2 + 4], "info": rec[:, :, C2 + 5]}
+        assert layout == "columns"
         t = {"dice": torch.zeros((K, N), dtype=torch.int8, device=dev),
              "action": torch.zeros((K, N, 2), dtype=torch.int8, device=dev),
              "reward": torch.zeros((K, N), dtype=torch.float64, device=dev),
@@ -174,10 +194,11 @@ class VecEWN:
         traj, totals = traj or {}, totals or {}
         for v in traj.values():
             assert v.shape[0] >= K and v.shape[1] == self.N
-        out = EwnRolloutOut(_ptr(traj.get("board")), _ptr(traj.get("dice")), _ptr(traj.get("action")), _ptr(traj.get("reward")),
-                            _ptr(traj.get("terminated")), _ptr(traj.get("truncated")), _ptr(traj.get("info")),
+        col = (lambda k: None) if "record" in traj else traj.get   # record layout: the column entries are views, not buffers
+        out = EwnRolloutOut(_ptr(col("board")), _ptr(col("dice")), _ptr(col("action")), _ptr(traj.get("reward")),
+                            _ptr(col("terminated")), _ptr(col("truncated")), _ptr(col("info")),
                             _ptr(totals.get("return_sum")), _ptr(totals.get("n_steps")), _ptr(totals.get("n_episodes")),
-                            _ptr(totals.get("n_wins")))
+                            _ptr(totals.get("n_wins")), _ptr(traj.get("record")))
         check(self.lib.ewn_step_k(C.byref(self.cfg), C.byref(self._st), int(K), AGENT[agent], int(agent_max_depth), C.byref(out),
                                   _stream()), "ewn_step_k")
         return self.board, self.dice

@@ -34,7 +34,8 @@
 extern "C" {
 #endif
 
-#define EWN_ABI_VERSION 3 /* 2: ewn_step_k, ewn_predict_minimax_sim, ewn_lanes_per_game; six table images; boards up to 11x11.  3: EWN_AGENT_SAMPLE; 32 KB table images */
+#define EWN_ABI_VERSION 4 /* 2: ewn_step_k, ewn_predict_minimax_sim, ewn_lanes_per_game; six table images; boards up to 11x11.  3: EWN_AGENT_SAMPLE; 32 KB table images.
+                             4: ewn_rollout_out.record, ewn_roll_dice, EWN_AGENT_MLP / ewn_policy, shaped env and MCTS opponent in ewn_step_k, ewn_a2c_* */
 
 /* error codes */
 #define EWN_OK 0
@@ -161,6 +162,11 @@ int ewn_init_aux(const ewn_config *cfg, const ewn_state *st, void *stream);
  * lane's stored next_seed) is the argument of np.random.seed. */
 int ewn_reset(const ewn_config *cfg, const ewn_state *st, const uint32_t *seeds, const uint8_t *lane_mask, void *stream);
 
+/* EinsteinWuerfeltNichtEnv.roll_dice (envs/ewn.py:90-92): dice_roll = np.random.randint(1, cube_num + 1), one draw from the
+ * lane's own dice stream, for every lane with lane_mask[i] != 0 (NULL = all lanes) whose game is not finished.  The step
+ * and reset entry points roll their dice themselves; this is the public method on its own. */
+int ewn_roll_dice(const ewn_config *cfg, const ewn_state *st, const uint8_t *lane_mask, void *stream);
+
 /* EinsteinWuerfeltNichtEnv.step (envs/ewn.py:436-486) or, with cfg->shaped,
  * MiniMaxHeuristicEnv.step (envs/training_ewn.py:43-99): agent move, win test,
  * opponent dice + reply (opponent_action, ewn.py:289-296, by cfg->opponent_kind),
@@ -195,7 +201,18 @@ typedef struct ewn_rollout_out {
     int32_t *n_steps;    /* [N] steps played (a finished, un-reset lane plays none) */
     int32_t *n_episodes; /* [N] episodes finished */
     int32_t *n_wins;     /* [N] of which won ("You won!", envs/ewn.py:454) */
+    /* The same trajectory as ONE record per lane-step, [K][N][EWN_TRAJ_RECORD_STRIDE(S)] bytes, 16-byte aligned; may be NULL.
+     * Record = board int8 [S*S] | dice | action[2] | terminated | truncated | info | zero padding: a lane-step is one or two whole
+     * 32-byte sectors written with 16-byte stores (32 bytes for 5x5, 64 for 7x7) instead of a 25-byte row at an odd offset plus
+     * five 1-2 byte columns.  The reward stays in its own f64 column.  Independent of the columns above (any subset may be asked for). */
+    uint8_t *record;
 } ewn_rollout_out;
+#define EWN_TRAJ_RECORD_STRIDE(S) ((((S) * (S)) + 6 + 15) & ~15)
+#define EWN_TRAJ_REC_DICE(S) ((S) * (S))          /* byte offsets inside a record */
+#define EWN_TRAJ_REC_ACTION(S) ((S) * (S) + 1)
+#define EWN_TRAJ_REC_TERMINATED(S) ((S) * (S) + 3)
+#define EWN_TRAJ_REC_TRUNCATED(S) ((S) * (S) + 4)
+#define EWN_TRAJ_REC_INFO(S) ((S) * (S) + 5)
 
 /* Introspection: how many lanes of a wavefront share one game in the table-driven kernel this configuration runs -- entry 0:
  * ewn_step (given ewn_state.tables), entry 1: ewn_step_k with the RandomAgent agent; 0 = a generic kernel (one thread per game).

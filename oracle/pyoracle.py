@@ -226,6 +226,12 @@ class OracleVecEnv:
         out = (b, d, r, te, tr, info)
         return out + (tb, td) if want_terminal else out
 
+    def roll_dice(self, mask=None):
+        """roll_dice (envs/ewn.py:90-92) on the selected lanes; returns the dice"""
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        lib().ewn_oracle_roll_dice(C.c_void_p(self.h), _p(m))
+        return self.obs()[1]
+
     def random_actions(self):
         a = np.zeros((self.N, 2), np.int8)
         lib().ewn_oracle_random_actions(C.c_void_p(self.h), _p(a))

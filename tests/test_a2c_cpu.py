@@ -193,3 +193,26 @@ def test_ppo_rejects_a_minibatch_larger_than_the_buffer():
     from ewn_gym_amd.ppo import PPOTrainer
     with pytest.raises(ValueError):
         PPOTrainer(_FakeEnv(8, 0), n_steps=2, batch_size=17, use_graph=False)
+
+
+def test_checkpoint_round_trip_and_algorithm_check(tmp_path):
+    """--checkpoint (train.py:137-139): model, optimiser, step counter, best score and the sampling generator come back; a
+    checkpoint of the other algorithm is refused with a clear error instead of mis-loading its optimiser state"""
+    import pytest
+    from ewn_gym_amd.a2c import A2CTrainer
+    from ewn_gym_amd.ppo import PPOTrainer
+    t = A2CTrainer(_FakeEnv(8, 0), n_steps=2, seed=3, device="cpu", use_graph=False)
+    t.best_score, t.num_timesteps = 0.4, 123
+    torch.rand(5, generator=t.gen)
+    path = str(tmp_path / "ck.pt")
+    t.save(path)
+    nxt = torch.rand(4, generator=t.gen)
+    u = A2CTrainer(_FakeEnv(8, 0), n_steps=2, seed=99, device="cpu", use_graph=False)
+    u.load(path)
+    assert u.best_score == 0.4 and u.num_timesteps == 123
+    assert torch.equal(torch.rand(4, generator=u.gen), nxt)
+    for a, b in zip(t.model.parameters(), u.model.parameters()):
+        assert torch.equal(a, b)
+    p = PPOTrainer(_FakeEnv(8, 0), n_steps=2, seed=3, device="cpu", use_graph=False)
+    with pytest.raises(ValueError, match="A2C trainer"):
+        p.load(path)

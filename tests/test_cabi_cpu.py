@@ -27,14 +27,14 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.ewn_abi_version() == 3
+    assert lib.ewn_abi_version() == 4
     assert lib.ewn_strerror(0) == b"ok" and b"invalid" in lib.ewn_strerror(-1)
 
 
 def test_struct_layout_matches_header():
     assert C.sizeof(EwnConfig) == 14 * 4 + 2 * 4 + 2 * 8 + 8
     assert C.sizeof(_lib.EwnState) == 7 * 8 and C.sizeof(_lib.EwnStepOut) == 7 * 8
-    assert C.sizeof(_lib.EwnRolloutOut) == 11 * 8
+    assert C.sizeof(_lib.EwnRolloutOut) == 12 * 8
 
 
 def test_step_k_availability_is_decided_on_the_host():

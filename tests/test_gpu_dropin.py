@@ -293,3 +293,20 @@ def test_sim_winrate_agent_through_the_drop_in_classes():
     m = envs.MinimaxEnv()
     v = m.evaluate("sim_winrate")
     assert 0.0 <= v <= 1.0
+
+
+def test_roll_dice_is_numpys_next_draw():
+    """envs/ewn.py:90-92: roll_dice() = np.random.randint(1, cube_num + 1) on the stream reset(seed) seeded -- the drop-in draws it on
+    the device from the env's own MT19937-compatible stream; numpy itself (legacy seed + randint) says what the values must be"""
+    import envs
+    for S, L in ((5, 3), (7, 4)):
+        env = envs.EinsteinWuerfeltNichtEnv(board_size=S, cube_layer=L)
+        for seed in (0, 7, 9487, 2 ** 32 - 1):
+            obs, _ = env.reset(seed=seed)
+            np.random.seed(seed)
+            exp = [int(np.random.randint(1, env.cube_num + 1)) for _ in range(9)]
+            got = [obs["dice_roll"]]
+            for _ in range(8):
+                env.roll_dice()
+                got.append(env.dice_roll)
+            assert got == exp, (S, L, seed)

@@ -195,6 +195,29 @@ def _lockstep(ea, N, steps, seed0=1000, check_terminal=True, **kw):
 
 
 @pytest.mark.parametrize("rng", ["mt19937", "philox"])
+def test_roll_dice_vs_oracle(ea, rng):
+    """ewn_roll_dice (envs/ewn.py:90-92) on masked lanes, interleaved with steps: dice and the streams behind them stay the oracle's"""
+    N = 2000
+    kw = dict(opponent_policy="random", rng=rng, philox_key=77)
+    env = ea.VecEWN(N, autoreset=False, **kw)
+    orc = po.OracleVecEnv(N, opponent="random", autoreset=False, rng=rng, philox_key=77)
+    seeds = np.arange(N, dtype=np.uint32) * 13 + 5
+    env.reset(seeds=seeds)
+    orc.reset(seeds=seeds)
+    gen = np.random.Generator(np.random.PCG64(3))
+    for t in range(25):
+        mask = (gen.integers(0, 3, N) > 0).astype(np.uint8) if t % 2 else None
+        d = cpu(env.roll_dice(mask))
+        assert np.array_equal(d, orc.roll_dice(mask)), t
+        acts = orc.sample_legal_actions(t)
+        res = [cpu(x) for x in env.step(acts)]
+        ores = orc.step(acts)
+        for a, o in zip(res, ores):
+            assert np.array_equal(a, o), t
+    assert cpu(env.done).sum() > N // 2     # finished lanes kept their dice through the later calls
+
+
+@pytest.mark.parametrize("rng", ["mt19937", "philox"])
 def test_step_random_opponent_vs_oracle(ea, rng):
     assert _lockstep(ea, 3000, 40, rng=rng, philox_key=0x1234ABCD5678) > 3000
 

@@ -26,7 +26,7 @@ def cpu(t):
     return t.detach().cpu().numpy()
 
 
-def _rollout_vs_oracle(ea, N, lo, hi, K, launches, agent="random", agent_max_depth=3, autoreset=True, board_column=True, **kw):
+def _rollout_vs_oracle(ea, N, lo, hi, K, launches, agent="random", agent_max_depth=3, autoreset=True, board_column=True, layout="columns", **kw):
     okw = dict(kw)
     opp = okw.pop("opponent_policy")
     env = ea.VecEWN(N, opponent_policy=opp, autoreset=autoreset, seed_stride=N, **okw)
@@ -36,7 +36,8 @@ def _rollout_vs_oracle(ea, N, lo, hi, K, launches, agent="random", agent_max_dep
     S, L = kw.get("board_size", 5), 3
     orc = po.OracleVecEnv(hi - lo, opponent=opp, autoreset=autoreset, seed_stride=N, lane_offset=lo, **okw)
     ob, od = orc.reset(seeds=seeds[lo:hi])
-    traj = env.alloc_rollout(K, board=board_column)
+    traj = env.alloc_rollout(K, board=board_column, layout=layout)
+    board_column = board_column or layout == "record"
     totals = env.alloc_totals()
     frozen = np.zeros(hi - lo, bool)
     ret = np.zeros(hi - lo)
@@ -132,6 +133,48 @@ def test_rollout_action_space_sample_agent(ea, N, lo, kw):
     assert n > 100         # episodes ended (and restarted) inside the launches
 
 
+@pytest.mark.parametrize("N,lo,kw", [
+    (SLOT_N, 30000, dict(max_depth=3)), (SLOT_N, 100, dict(max_depth=3, board_size=6)), (SLOT_N, 65000, dict(max_depth=4, board_size=7)),
+    (SLOT_N, 2000, dict(max_depth=5, board_size=8)), (140000, 139000, dict(max_depth=3)), (140000, 64, dict(max_depth=2, board_size=7)),
+    (1500, 0, dict(max_depth=3)), (40000, 30000, dict(max_depth=3, board_size=6)), (900, 100, dict(max_depth=5, board_size=8)),
+    (3000, 1000, dict(opponent="random")), (3000, 0, dict(opponent="random", board_size=7)),
+], ids=lambda v: str(v) if not isinstance(v, dict) else "-".join("%s=%s" % kv for kv in sorted(v.items())))
+def test_rollout_record_layout(ea, N, lo, kw):
+    """ewn_rollout_out.record: one 16-byte aligned record per lane-step (board | dice | action | flags), the board bytes kept
+    current in LDS move by move (slot-task kernel) or re-encoded per step (lock-step kernel): every byte against the oracle,
+    both kernels, one and two lanes per game, 5x5 .. 8x8, auto-resets inside the launches."""
+    kw = dict(kw)
+    opp = kw.pop("opponent", "minimax")
+    n = _rollout_vs_oracle(ea, N, lo, lo + (96 if kw.get("max_depth", 3) >= 5 else 200), 9, 3, layout="record", opponent_policy=opp,
+                           rng="philox", philox_key=99, **kw)
+    assert n > 100
+
+
+def test_rollout_record_padding_is_zero_and_columns_agree(ea):
+    """record and separate columns asked for together describe the same trajectory; padding bytes stay zero; frozen lanes (no
+    auto-reset) and the action_space.sample() agent (illegal moves) included"""
+    from ewn_gym_amd.vec_env import _ptr  # noqa: F401
+    for N, S, agent, autoreset in ((SLOT_N, 5, "sample", True), (2000, 7, "random", False), (SLOT_N, 6, "random", False)):
+        env = ea.VecEWN(N, board_size=S, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=5, autoreset=autoreset, seed_stride=N)
+        env.reset(seeds=(np.arange(N, dtype=np.uint64) + 11).astype(np.uint32))
+        K = 12
+        cols = env.alloc_rollout(K)
+        rec = env.alloc_rollout(K, layout="record")
+        both = dict(cols)
+        both["record"] = rec["record"]
+        # hand both the columns and the record to one call (rollout() drops the columns when it sees a record: call the ABI directly)
+        import ctypes as C
+        from ewn_gym_amd._lib import AGENT, EwnRolloutOut
+        from ewn_gym_amd.vec_env import _ptr, _stream
+        out = EwnRolloutOut(_ptr(cols["board"]), _ptr(cols["dice"]), _ptr(cols["action"]), _ptr(cols["reward"]), _ptr(cols["terminated"]),
+                            _ptr(cols["truncated"]), _ptr(cols["info"]), None, None, None, None, _ptr(rec["record"]))
+        assert env.lib.ewn_step_k(C.byref(env.cfg), C.byref(env._st), K, AGENT[agent], 3, C.byref(out), _stream()) == 0
+        for key in ("board", "dice", "action", "terminated", "truncated", "info"):
+            assert torch.equal(rec[key], cols[key]), (N, S, key)
+        assert int(rec["record"][:, :, S * S + 6:].max()) == 0
+        assert int(cols["terminated"].sum()) > 0
+
+
 def test_rollout_slot_task_kernel_short_launches(ea):
     """K = 1, 2, 3: a launch ends after every game has played exactly K steps, however many of them needed a second iteration"""
     for K in (1, 2, 3):
@@ -145,6 +188,13 @@ def test_rollout_slot_task_kernel_frozen_lanes_and_numpy_dice(ea):
     _rollout_vs_oracle(ea, SLOT_N, 65000, 65300, 9, 2, autoreset=False, opponent_policy="minimax", max_depth=5, rng="mt19937", board_column=False)
     _rollout_vs_oracle(ea, 140000, 139700, 140000, 11, 3, autoreset=False, opponent_policy="minimax", max_depth=3, rng="mt19937")
     _rollout_vs_oracle(ea, 140000, 0, 200, 6, 2, opponent_policy="minimax", max_depth=5, rng="philox", philox_key=5, board_column=False)
+
+
+def test_config2_random_opponent_at_its_own_shape(ea):
+    """BASELINE config 2 at its own shape (5x5, 65 536 lanes, RandomAgent opponent): ewn_step_k against the oracle on two slices,
+    both trajectory layouts (the launcher's kernel choice depends on the lane count)"""
+    _rollout_vs_oracle(ea, 65536, 0, 300, 10, 3, opponent_policy="random", rng="philox", philox_key=2024)
+    _rollout_vs_oracle(ea, 65536, 65236, 65536, 10, 3, opponent_policy="random", rng="philox", philox_key=2024, layout="record")
 
 
 def test_rollout_random_opponent_and_mt19937_without_autoreset(ea):
