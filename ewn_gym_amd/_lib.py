@@ -23,8 +23,9 @@ INFO_MESSAGES = {
 EXPORTS = ["ewn_abi_version", "ewn_strerror", "ewn_rng_words", "ewn_step_scratch_bytes", "ewn_tables_bytes",
            "ewn_build_tables", "ewn_init_aux", "ewn_reset",
            "ewn_step", "ewn_legal_actions", "ewn_apply_action", "ewn_playout_wins", "ewn_evaluate", "ewn_predict_minimax", "ewn_predict_random",
-           "ewn_predict_mcts", "ewn_step_k", "ewn_step_k_supported", "ewn_predict_minimax_sim", "ewn_lanes_per_game", "ewn_roll_dice"]
-AGENT = {"random": 0, "minimax": 1, "sample": 2}   # "sample": env.action_space.sample(), all six actions (EWN_AGENT_SAMPLE)
+           "ewn_predict_mcts", "ewn_step_k", "ewn_step_k_supported", "ewn_predict_minimax_sim", "ewn_lanes_per_game", "ewn_roll_dice",
+           "ewn_policy_param_count", "ewn_step_k_policy", "ewn_a2c_scratch_bytes", "ewn_a2c_grad", "ewn_a2c_apply"]
+AGENT = {"random": 0, "minimax": 1, "sample": 2, "mlp": 3}   # "mlp": the trained policy, through ewn_step_k_policy   # "sample": env.action_space.sample(), all six actions (EWN_AGENT_SAMPLE)
 
 
 class EwnConfig(C.Structure):  # struct ewn_config
@@ -55,6 +56,16 @@ class EwnRolloutOut(C.Structure):  # struct ewn_rollout_out
                 ("terminated", C.c_void_p), ("truncated", C.c_void_p), ("info", C.c_void_p),
                 ("return_sum", C.c_void_p), ("n_steps", C.c_void_p), ("n_episodes", C.c_void_p), ("n_wins", C.c_void_p),
                 ("record", C.c_void_p)]
+
+
+class EwnPolicy(C.Structure):  # struct ewn_policy
+    _fields_ = [("params", C.c_void_p), ("deterministic", C.c_int32), ("record_initial_obs", C.c_int32), ("noise_key", C.c_uint64),
+                ("logits", C.c_void_p), ("value", C.c_void_p), ("noise", C.c_void_p)]
+
+
+class EwnA2cHyper(C.Structure):  # struct ewn_a2c_hyper
+    _fields_ = [("gamma", C.c_float), ("vf_coef", C.c_float), ("ent_coef", C.c_float), ("max_grad_norm", C.c_float),
+                ("learning_rate", C.c_float), ("rms_alpha", C.c_float), ("rms_eps", C.c_float), ("world_size", C.c_int32)]
 
 
 class EwnError(RuntimeError):
@@ -106,6 +117,11 @@ def load():
         "ewn_step_k": (i32, [cfgp, stp, i32, i32, i32, C.POINTER(EwnRolloutOut), vp]),
         "ewn_step_k_supported": (i32, [cfgp, i32, i32]),
         "ewn_lanes_per_game": (i32, [cfgp, i32]),
+        "ewn_policy_param_count": (C.c_int64, [i32, i32]),
+        "ewn_step_k_policy": (i32, [cfgp, stp, i32, C.POINTER(EwnPolicy), C.POINTER(EwnRolloutOut), vp]),
+        "ewn_a2c_scratch_bytes": (C.c_int64, [cfgp, i32]),
+        "ewn_a2c_grad": (i32, [cfgp, i32, vp, vp, vp, C.POINTER(EwnA2cHyper), vp, vp, vp]),
+        "ewn_a2c_apply": (i32, [cfgp, vp, vp, vp, C.POINTER(EwnA2cHyper), vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -75,6 +75,19 @@ class ActorCritic(nn.Module):
         nn.init.orthogonal_(self.value_net.weight, gain=1.0)
         nn.init.zeros_(self.value_net.bias)
 
+    def flat_parameters(self):
+        """the parameters as ONE fp32 vector in the order the HIP kernels read them (include/ewn_hip.h, struct ewn_policy): body pi
+        (W1, b1, W2, b2), body vf, action head (W, b), value head (W, b) -- the order of .parameters()"""
+        return torch.cat([p.detach().reshape(-1) for p in self.parameters()]).to(torch.float32).contiguous()
+
+    def load_flat_parameters(self, flat):
+        off = 0
+        with torch.no_grad():
+            for p in self.parameters():
+                p.copy_(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+        assert off == flat.numel()
+
     def features(self, board, dice):
         """board int8 [N,S,S], dice int8 [N] (1..cube_num) -> float32 [N, S*S + cube_num + 1]"""
         b = board.reshape(board.shape[0], -1).to(torch.float32)
@@ -266,3 +279,114 @@ class A2CTrainer:
             self.gen.set_state(sd["generator"].cpu())
         self._graph = None           # a captured rollout holds the old generator registration
         self._warm = False
+
+
+class FusedA2CTrainer:
+    """A2C with the whole loop in the engine (BASELINE config 4): the n-step rollout is ONE kernel (ewn_step_k_policy: policy
+    network on the matrix cores, Gumbel-max sampling, shaped env step, opponent search, records), the update three more
+    (ewn_a2c_grad: value pass, policy pass, reduction; ewn_a2c_apply: global-norm clip + RMSprop) -- no torch operator on the
+    training path, one all-reduce of the flat gradient between grad and apply when there are several ranks.  Same loss and
+    optimiser as A2CTrainer (SB3's documented A2C defaults, gae_lambda = 1); the parameters live in ONE flat fp32 tensor that the
+    torch module `self.model` views (evaluation, checkpoints)."""
+
+    algorithm = "A2C"
+    best_score = -1.0
+
+    def __init__(self, env, n_steps=5, learning_rate=7e-4, gamma=0.99, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, seed=None,
+                 rms_alpha=0.99, rms_eps=1e-5, use_graph=True):
+        import ctypes as C
+        from . import _lib
+        if not env.supports_policy_rollout():
+            raise _lib.EwnError("this env configuration has no policy-driven rollout kernel (ewn_step_k_policy): use A2CTrainer")
+        self.env, self.lib, self.C = env, env.lib, C
+        self.device = env.board.device
+        if seed is not None:
+            torch.manual_seed(seed)
+        self.model = ActorCritic(env.S, env.cube_num).to(self.device)
+        self.params = self.model.flat_parameters()                    # the flat vector the kernels read and update in place
+        off = 0
+        for p in self.model.parameters():                             # ... and the module's parameters become views of it
+            p.data = self.params[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        assert off == env.policy_param_count()
+        self._sync_parameters()
+        self.sq_avg = torch.zeros_like(self.params)
+        self.grad = torch.zeros(self.params.numel() + 8, dtype=torch.float32, device=self.device)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.n_steps, self.num_timesteps = int(n_steps), 0
+        world = 1
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            world = dist.get_world_size()
+        self.world = world
+        self.hyper = _lib.EwnA2cHyper(float(gamma), float(vf_coef), float(ent_coef), float(max_grad_norm), float(learning_rate),
+                                      float(rms_alpha), float(rms_eps), int(world))
+        nscr = _lib.check(self.lib.ewn_a2c_scratch_bytes(C.byref(env.cfg), self.n_steps), "ewn_a2c_scratch_bytes")
+        self.scratch = torch.zeros(int(nscr), dtype=torch.uint8, device=self.device)
+        self.traj = env.alloc_rollout(self.n_steps, layout="record", initial_obs=True)
+        self.noise_key = (0 if seed is None else int(seed)) * 0x9E3779B97F4A7C15 & 0xFFFFFFFFFFFFFFFF
+        self.gen = torch.Generator(device=self.device)                # policy_fn's sampling only (evaluation is deterministic)
+        self.gen.manual_seed(0 if seed is None else int(seed))
+        self.use_graph = use_graph and world == 1
+        self._graph = None
+        self._warm = False
+
+    _sync_parameters = A2CTrainer._sync_parameters
+
+    def _launch(self):
+        from ._lib import check
+        from .vec_env import _ptr, _stream
+        C, env = self.C, self.env
+        env.rollout_policy(self.n_steps, self.params, traj=self.traj, noise_key=self.noise_key)
+        check(self.lib.ewn_a2c_grad(C.byref(env.cfg), self.n_steps, _ptr(self.traj["record"]), _ptr(self.traj["reward"]), _ptr(self.params),
+                                    C.byref(self.hyper), _ptr(self.grad), _ptr(self.scratch), _stream()), "ewn_a2c_grad")
+        if self.world > 1:   # the one collective of the training path: the flat gradient (52 KB), summed; apply divides by the world size
+            import torch.distributed as dist
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
+        check(self.lib.ewn_a2c_apply(C.byref(env.cfg), _ptr(self.params), _ptr(self.sq_avg), _ptr(self.grad), C.byref(self.hyper),
+                                     _ptr(self.grad_norm), _stream()), "ewn_a2c_apply")
+
+    def collect_and_update(self):
+        if self.use_graph and self._warm:
+            if self._graph is None:       # five kernel launches, no torch operator: captured once, replayed per update
+                torch.cuda.synchronize()
+                self._graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph):
+                    self._launch()
+            self._graph.replay()
+        else:
+            self._launch()
+            self._warm = True
+        self.num_timesteps += self.n_steps * self.env.N
+        return self.grad
+
+    def stats_dict(self):
+        g = self.grad[-8:].tolist()
+        n = float(self.n_steps * self.env.N * self.world)
+        pl, vl, en = g[0] / n, g[5] / n, g[2] / n
+        return {"loss": pl + self.hyper.vf_coef * vl - self.hyper.ent_coef * en, "policy_loss": pl, "value_loss": vl, "entropy": en,
+                "mean_reward": float(self.traj["reward"].mean()), "episodes": int(self.traj["terminated"].sum()),
+                "grad_norm": float(self.grad_norm)}
+
+    def learn(self, total_timesteps):
+        target = self.num_timesteps + total_timesteps
+        while self.num_timesteps < target:
+            self.collect_and_update()
+        return self.stats_dict()
+
+    def policy_fn(self, deterministic=True):
+        return lambda b, d, t: self.model.act(b, d, deterministic=deterministic, generator=self.gen)[0]
+
+    def save(self, path):
+        torch.save({"algorithm": self.algorithm, "fused": True, "params": self.params, "sq_avg": self.sq_avg,
+                    "num_timesteps": self.num_timesteps, "best_score": float(self.best_score)}, path)
+
+    def load(self, path):
+        sd = torch.load(path, map_location=self.device, weights_only=True)
+        if sd.get("algorithm", "A2C") != self.algorithm or not sd.get("fused", False):
+            raise ValueError("checkpoint %s was not written by the fused A2C trainer" % path)
+        self.params.copy_(sd["params"])
+        self.sq_avg.copy_(sd["sq_avg"])
+        self.num_timesteps = sd["num_timesteps"]
+        self.best_score = float(sd.get("best_score", -1.0))
+

@@ -112,6 +112,15 @@ static inline int64_t fast_tables_bytes(int S, int L)
     }
 }
 
+// table image of a search with the given heuristic and max_depth: max_depth 4 and 6 read the image's second variant (leaves
+// averaged over six dice); NULL for a heuristic without images
+static inline const void *fast_image(const void *tables, int S, int L, int max_depth, int heur = EWN_H_HYBRID)
+{
+    const int hi = fast_heur_image(heur);
+    if (!tables || hi < 0) return nullptr;
+    return (const int8_t *)tables + (size_t)(hi * 2 + ((max_depth == 4 || max_depth == 6) ? 1 : 0)) * fast_tables_bytes(S, L);
+}
+
 // Lanes of one wavefront that share a game in k_step_d3: enough to put several waves on every SIMD
 // (1024 SIMDs x 64 lanes) at the given number of games.  EWN_D3_T=0 disables the kernel, 1 / 2 forces T.
 static inline int d3_threads_per_game(int n_games)
@@ -169,3 +178,5 @@ int ewn_launch_rollout_s5(const RollCfg &rc, const RollBuf &rb, int T, int opp, 
 int ewn_launch_rollout_s6(const RollCfg &rc, const RollBuf &rb, int T, int opp, int rngk, int agent, hipStream_t s);
 int ewn_launch_rollout_s7(const RollCfg &rc, const RollBuf &rb, int T, int opp, int rngk, int agent, hipStream_t s);
 int ewn_launch_rollout_s8(const RollCfg &rc, const RollBuf &rb, int T, int opp, int rngk, int agent, hipStream_t s);
+// ewn_policy.hip: the policy-driven rollout (ewn_step_k_policy); EWN_OK when it serves the configuration
+int ewn_policy_supported(const ewn_config *cfg, const Geom &g);

@@ -866,7 +866,6 @@ static int mcts_launch(const Geom &g, int M, const int8_t *boards, const int8_t 
     return launch_status();
 }
 
-static const void *fast_image(const void *tables, int S, int L, int max_depth, int heur);
 
 int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, const ewn_step_out *out, void *scratch, void *stream)
 {
@@ -932,14 +931,6 @@ int ewn_step(const ewn_config *cfg, const ewn_state *st, const int8_t *actions, 
     return rc;
 }
 
-// table image of a search with the given heuristic and max_depth: max_depth 4 and 6 read the image's second variant (leaves
-// averaged over six dice); NULL for a heuristic without images
-static const void *fast_image(const void *tables, int S, int L, int max_depth, int heur = EWN_H_HYBRID)
-{
-    const int hi = fast_heur_image(heur);
-    if (!tables || hi < 0) return nullptr;
-    return (const int8_t *)tables + (size_t)(hi * 2 + ((max_depth == 4 || max_depth == 6) ? 1 : 0)) * fast_tables_bytes(S, L);
-}
 
 // which k_rollout_d3 instantiation serves (cfg, agent): EWN_OK and the template selectors, or why not
 static int rollout_plan(const ewn_config *cfg, const Geom &g, const KCfg &k, int agent_kind, int agent_max_depth, int &T, int &opp, int &agent)
@@ -990,6 +981,7 @@ int ewn_step_k_supported(const ewn_config *cfg, int agent_kind, int agent_max_de
     Geom g; KCfg k;
     int rc = check_cfg(cfg, g, k);
     if (rc) return rc;
+    if (agent_kind == EWN_AGENT_MLP) { rc = ewn_policy_supported(cfg, g); return rc == EWN_OK ? 1 : (rc == EWN_EUNSUPPORTED ? 0 : rc); } // ewn_step_k_policy
     int T, opp, agent;
     rc = rollout_plan(cfg, g, k, agent_kind, agent_max_depth, T, opp, agent);
     return rc == EWN_OK ? 1 : (rc == EWN_EUNSUPPORTED ? 0 : rc);

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import AGENT, HEUR, OPP, RNG, EwnConfig, EwnRolloutOut, EwnState, EwnStepOut, check
+from ._lib import AGENT, HEUR, OPP, RNG, EwnConfig, EwnPolicy, EwnRolloutOut, EwnState, EwnStepOut, check
 
 
 def _require_gpu(device):
@@ -156,7 +156,7 @@ class VecEWN:
             return False
         return self.lib.ewn_step_k_supported(C.byref(self.cfg), AGENT[agent], int(agent_max_depth)) == 1
 
-    def alloc_rollout(self, K, board=True, layout="columns"):
+    def alloc_rollout(self, K, board=True, layout="columns", initial_obs=False):
         """Trajectory buffers for rollout(K, traj=...): dict of [K, N, ...] tensors (the observation column is optional).
         layout="record": ONE 16-byte aligned record per lane-step (ewn_rollout_out.record: board | dice | action | terminated |
         truncated | info | padding; 32 bytes for 5x5) plus the f64 reward column; the dict's board / dice / action / flag entries
@@ -165,11 +165,18 @@ class VecEWN:
         if layout == "record":
             C2 = S * S
             stride = (C2 + 6 + 15) & ~15
-            rec = torch.zeros((K, N, stride), dtype=torch.uint8, device=dev)
-            return {"record": rec, "reward": torch.zeros((K, N), dtype=torch.float64, device=dev),
-                    "board": rec[:, :, :C2].view(torch.int8).unflatten(2, (S, S)), "dice": rec[:, :, C2].view(torch.int8),
-                    "action": rec[:, :, C2 + 1:C2 + 3].view(torch.int8), "terminated": rec[:, :, C2 + 3],
-                    "truncated": rec[:, :, C2 + 4], "info": rec[:, :, C2 + 5]}
+            # initial_obs (rollout_policy(record_initial_obs=True)): one more row in front, the observation before step 0; the
+            # per-step views below then start at row 1 and "obs_board" / "obs_dice" are the K + 1 observations s_0 .. s_K
+            full = torch.zeros((K + (1 if initial_obs else 0), N, stride), dtype=torch.uint8, device=dev)
+            rec = full[1:] if initial_obs else full
+            t = {"record": full, "reward": torch.zeros((K, N), dtype=torch.float64, device=dev),
+                 "board": rec[:, :, :C2].view(torch.int8).unflatten(2, (S, S)), "dice": rec[:, :, C2].view(torch.int8),
+                 "action": rec[:, :, C2 + 1:C2 + 3].view(torch.int8), "terminated": rec[:, :, C2 + 3],
+                 "truncated": rec[:, :, C2 + 4], "info": rec[:, :, C2 + 5]}
+            if initial_obs:
+                t["obs_board"] = full[:, :, :C2].view(torch.int8).unflatten(2, (S, S))
+                t["obs_dice"] = full[:, :, C2].view(torch.int8)
+            return t
         assert layout == "columns"
         t = {"dice": torch.zeros((K, N), dtype=torch.int8, device=dev),
              "action": torch.zeros((K, N, 2), dtype=torch.int8, device=dev),
@@ -201,6 +208,33 @@ class VecEWN:
                             _ptr(totals.get("n_wins")), _ptr(traj.get("record")))
         check(self.lib.ewn_step_k(C.byref(self.cfg), C.byref(self._st), int(K), AGENT[agent], int(agent_max_depth), C.byref(out),
                                   _stream()), "ewn_step_k")
+        return self.board, self.dice
+
+    # -- K env steps per launch with the trained policy as the agent (ewn_step_k_policy; train.py:134, 148's rollout collection)
+    def policy_param_count(self):
+        return int(check(self.lib.ewn_policy_param_count(self.S, self.L), "ewn_policy_param_count"))
+
+    def supports_policy_rollout(self):
+        return self.tables is not None and self.lib.ewn_step_k_supported(C.byref(self.cfg), AGENT["mlp"], 0) == 1
+
+    def rollout_policy(self, K, params, traj=None, totals=None, deterministic=False, noise_key=0, logits=None, value=None, noise=None):
+        """Play K steps of every lane in one launch, actions sampled from the actor-critic whose flat fp32 parameter vector is
+        `params` (a2c.ActorCritic.flat order).  traj: dict from alloc_rollout (a record layout allocated with initial_obs=True gets
+        K + 1 rows); logits [K, N, 5] / value [K, N] / noise [K, N, 5] float32: optional per-step outputs of the policy."""
+        traj, totals = traj or {}, totals or {}
+        assert params.dtype == torch.float32 and params.is_contiguous() and params.numel() == self.policy_param_count()
+        rec0 = 0
+        if "record" in traj:
+            rec0 = 1 if "obs_board" in traj else 0
+            assert traj["record"].shape[0] >= K + rec0
+        col = (lambda k: None) if "record" in traj else traj.get
+        out = EwnRolloutOut(_ptr(col("board")), _ptr(col("dice")), _ptr(col("action")), _ptr(traj.get("reward")),
+                            _ptr(col("terminated")), _ptr(col("truncated")), _ptr(col("info")),
+                            _ptr(totals.get("return_sum")), _ptr(totals.get("n_steps")), _ptr(totals.get("n_episodes")),
+                            _ptr(totals.get("n_wins")), _ptr(traj.get("record")))
+        pol = EwnPolicy(_ptr(params), int(bool(deterministic)), rec0, int(noise_key) & 0xFFFFFFFFFFFFFFFF, _ptr(logits), _ptr(value), _ptr(noise))
+        check(self.lib.ewn_step_k_policy(C.byref(self.cfg), C.byref(self._st), int(K), C.byref(pol), C.byref(out), _stream()),
+              "ewn_step_k_policy")
         return self.board, self.dice
 
     def set_obs(self, boards, dice):

@@ -226,6 +226,65 @@ int ewn_step_k_supported(const ewn_config *cfg, int agent_kind, int agent_max_de
 int ewn_step_k(const ewn_config *cfg, const ewn_state *st, int K, int agent_kind, int agent_max_depth,
                const ewn_rollout_out *out, void *stream);
 
+/* ---- K env steps per launch with the TRAINED policy as the agent: the rollout collector of train.py:35-63, 134, 148 -----------
+ * (SB3 A2C("MultiInputPolicy", env, policy_kwargs=dict(activation_fn=Tanh)).learn -> collect_rollouts over SubprocVecEnv workers)
+ * as one kernel: observation -> features (S*S board cells as floats ++ one_hot(dice_roll - 1), width cube_num + 1 = 7,
+ * envs/ewn.py:66-68) -> policy network (SB3's default net_arch: two separate hidden-64-64 tanh bodies, 5 logits for
+ * MultiDiscrete([2, 3]) and a scalar value) on the matrix cores in exact fp32 -> Gumbel-max sample -> env step (plain or
+ * cfg->shaped: envs/training_ewn.py:43-99) -> opponent reply -> auto-reset.  Served for cube_layer 3, board sizes 5 and 7,
+ * opponent RandomAgent or minimax max_depth 1..4 with a (level, count) heuristic image, Philox dice. */
+#define EWN_AGENT_MLP 3     /* agent_kind of ewn_step_k_supported for this path (ewn_step_k itself takes no parameters: use ewn_step_k_policy) */
+#define EWN_POLICY_HIDDEN 64
+#define EWN_POLICY_LOGITS 5
+
+typedef struct ewn_policy {
+    const float *params;        /* [ewn_policy_param_count()] fp32, device: body pi {W1 [64][F], b1 [64], W2 [64][64], b2 [64]}, body vf
+                                   {same}, action head {W [5][64], b [5]}, value head {W [1][64], b [1]}; F = S*S + 7; row-major
+                                   [out][in] like torch.nn.Linear.weight -- the order of a2c.ActorCritic.parameters() */
+    int32_t deterministic;      /* 1: argmax of the logits (model.predict(deterministic=True), train.py:93) instead of sampling */
+    int32_t record_initial_obs; /* 1: ewn_rollout_out.record has K + 1 rows, row 0 = the observation before step 0 (meta bytes:
+                                   its dice, zeros) and row k + 1 = step k; what an n-step update needs (s_0 .. s_K) */
+    uint64_t noise_key;         /* keys the sampling noise together with cfg->philox_key, the global lane id, the episode seed
+                                   and the episode's draw count (the hash stream of ewn_step_out.random_action) */
+    /* per-step outputs of the policy, [K][N]...; each may be NULL */
+    float *logits;              /* [K][N][5] */
+    float *value;               /* [K][N]; non-NULL makes the kernel evaluate the value body too */
+    float *noise;               /* [K][N][5] the uniforms u in (0, 1) behind the Gumbel noise -log(-log u) of that step */
+} ewn_policy;
+
+/* number of fp32 parameters of the actor-critic for this geometry (< 0: not served) */
+int64_t ewn_policy_param_count(int board_size, int cube_layer);
+/* K >= 1 steps of every lane, the agent's action sampled from the policy; out may be NULL.  One kernel launch, no scratch. */
+int ewn_step_k_policy(const ewn_config *cfg, const ewn_state *st, int K, const ewn_policy *pol, const ewn_rollout_out *out, void *stream);
+
+/* ---- the A2C update on the records of ewn_step_k_policy: stable_baselines3 A2C.train as train.py:35-63, 148 configures it ----
+ * (n-step returns = GAE with lambda 1, no advantage normalisation; loss = policy gradient + vf_coef * MSE(returns, values) +
+ * ent_coef * (-entropy), a mean over the n_steps x lanes batch; clip_grad_norm_(max_grad_norm); RMSprop(alpha, eps)).  SB3 is not
+ * vendored: parity with it is unpinned, the arithmetic is checked against torch autograd of the same loss.  Forward (recomputed from
+ * the records: the parameters have not changed since the rollout) and backward run on the matrix cores in exact fp32. */
+typedef struct ewn_a2c_hyper {
+    float gamma;            /* 0.99 */
+    float vf_coef;          /* 0.5 */
+    float ent_coef;         /* 0.0 */
+    float max_grad_norm;    /* 0.5; <= 0: no clipping */
+    float learning_rate;    /* SB3 A2C default 7e-4; train.py passes its own (3e-4) */
+    float rms_alpha;        /* 0.99 */
+    float rms_eps;          /* 1e-5 */
+    int32_t world_size;     /* ewn_a2c_apply divides the (all-reduced, summed) gradient by it */
+} ewn_a2c_hyper;
+
+/* bytes of device scratch ewn_a2c_grad needs (advantages [K][N] + per-block partial gradients); < 0: configuration not served */
+int64_t ewn_a2c_scratch_bytes(const ewn_config *cfg, int K);
+/* record: [K + 1][N][EWN_TRAJ_RECORD_STRIDE(S)] written by ewn_step_k_policy with record_initial_obs = 1; reward [K][N].
+ * grad [ewn_policy_param_count() + 8]: the gradient of THIS rank's mean loss in the layout of ewn_policy.params, then the loss sums
+ * {policy, value, entropy, 0} of the policy pass and of the value pass (divide by K * N for means).  Three launches. */
+int ewn_a2c_grad(const ewn_config *cfg, int K, const uint8_t *record, const double *reward, const float *params, const ewn_a2c_hyper *hp,
+                 float *grad, void *scratch, void *stream);
+/* clip by the global norm, then one RMSprop step on params / sq_avg (both [param count], in place); grad_norm_out (may be NULL)
+ * receives the norm before clipping.  A multi-GPU job all-reduces (sums) grad between the two calls -- the one collective. */
+int ewn_a2c_apply(const ewn_config *cfg, float *params, float *sq_avg, const float *grad, const ewn_a2c_hyper *hp, float *grad_norm_out,
+                  void *stream);
+
 /* ---- stateless policy / rule queries on M given observations (canonical: TOP_LEFT to move) ---- */
 
 /* get_legal_actions (envs/ewn.py:338-375), find_cube_to_move (:178-215), check_win (:131-142).

@@ -232,6 +232,12 @@ class OracleVecEnv:
         lib().ewn_oracle_roll_dice(C.c_void_p(self.h), _p(m))
         return self.obs()[1]
 
+    def policy_noise(self, noise_key=0):
+        """[N, 5] float32: the uniforms ewn_step_k_policy turns into Gumbel noise at the lanes' current step"""
+        u = np.zeros((self.N, 5), np.float32)
+        lib().ewn_oracle_policy_noise(C.c_void_p(self.h), C.c_uint64(noise_key), _p(u))
+        return u
+
     def random_actions(self):
         a = np.zeros((self.N, 2), np.int8)
         lib().ewn_oracle_random_actions(C.c_void_p(self.h), _p(a))
