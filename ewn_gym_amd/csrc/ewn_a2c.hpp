@@ -143,10 +143,11 @@ __global__ __launch_bounds__(NWV * 64, 1) void k_a2c_grad(A2cCfg c, A2cBuf B)
                 for (int d = 0; d < 7; d++) XT[j * A::XS + CELLS + d] = (d == dice - 1) ? 1.0f : 0.0f;
             }
             __builtin_amdgcn_wave_barrier();
-            f32x16 h1[2], h2[2], out;
+            f32x16 h1[2], h2[2];
+            float out[NOUT];                     // the head's outputs of my sample, the same in both lane halves
             const float *xrow = XT + j * A::XS + h;
-            mlp_forward<S>(L, lane, [&](int s) { return xrow[2 * s]; }, h1, h2, out);
-            if (NET == 1 && t == c.K) { const float ov = mlp_other_half(out[0], lane); Rn = h ? ov : out[0]; continue; } // V(s_K), in both lane halves
+            mlp_forward<S, NOUT>(L, lane, [&](int s) { return xrow[2 * s]; }, h1, h2, out);
+            if (NET == 1 && t == c.K) { Rn = out[0]; continue; }   // V(s_K)
             // ---- the loss of step t and its gradient w.r.t. the head outputs (both lane halves hold the same numbers)
             const uint8_t *nrow = B.rec + ((size_t)(t + 1) * c.N + gc) * STR;   // row t + 1: action a_t, flags of step t
             float d[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
@@ -155,19 +156,13 @@ __global__ __launch_bounds__(NWV * 64, 1) void k_a2c_grad(A2cCfg c, A2cBuf B)
                 const bool term = nrow[CELLS + 3] != 0;
                 const float R = rew + (term ? 0.0f : c.gamma * Rn);
                 Rn = R;
-                const float ov = mlp_other_half(out[0], lane);
-                const float V = h ? ov : out[0];
+                const float V = out[0];
                 if (valid) {
                     if (h == 0) { B.adv[(size_t)t * c.N + game] = R - V; st_vl += (R - V) * (R - V); }
                     d[0] = 2.0f * c.vf_coef * (V - R) * c.inv_batch;
                 }
             } else {
-                float p[4], lg[5];
-                #pragma unroll
-                for (int i = 0; i < 4; i++) p[i] = mlp_other_half(out[i], lane);
-                #pragma unroll
-                for (int i = 0; i < 4; i++) lg[i] = h ? p[i] : out[i];
-                lg[4] = h ? out[0] : p[0];
+                const float (&lg)[NOUT] = out;
                 const int a0 = nrow[CELLS + 1], a1 = nrow[CELLS + 2];
                 const float adv = B.adv[(size_t)t * c.N + gc];
                 // log-softmax of the two categoricals (flag: logits 0-1, direction: logits 2-4)
@@ -337,19 +332,33 @@ __global__ __launch_bounds__(NWV * 64, 1) void k_a2c_grad(A2cCfg c, A2cBuf B)
 // ---- partials -> flat gradient (+ loss sums and the squared norm's per-block pieces)
 struct A2cRedBuf { const float *partial; const float *stats; float *grad; int blocks, P; };
 
+#define A2C_RED_E 32     // elements per block of k_a2c_reduce
 __global__ __launch_bounds__(256) void k_a2c_reduce(A2cRedBuf B)
 {
-    // grad[i] = sum over blocks of partial[b][i], fixed order; grad[P .. P + 7] = loss sums {policy, value, entropy, 0} x {pi pass, vf pass}
-    const int i = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    // grad[i] = sum over blocks of partial[b][i]; grad[P .. P + 7] = loss sums {policy, value, entropy, 0} x {pi pass, vf pass}.
+    // 32 elements per block, eight threads per element (each sums every eighth block with independent loads in flight, then the
+    // eight partial sums are added in a fixed order): the first version walked all blocks in one thread per element, a chain of
+    // 256 dependent-latency loads on 13 k threads (88 us for 13 MB).
+    __shared__ float part[8][A2C_RED_E];
+    const int e = (int)threadIdx.x & (A2C_RED_E - 1), q = (int)threadIdx.x / A2C_RED_E, i = (int)blockIdx.x * A2C_RED_E + e;
+    float s = 0.0f;
     if (i < B.P) {
-        float s = 0.0f;
-        for (int b = 0; b < B.blocks; b++) s += B.partial[(size_t)b * B.P + i];
-        B.grad[i] = s;
+        const float *p = B.partial + i;
+        float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        int b = q;
+        for (; b + 24 < B.blocks; b += 32) {
+            #pragma unroll
+            for (int u = 0; u < 4; u++) acc[u] += p[(size_t)(b + 8 * u) * B.P];
+        }
+        for (; b < B.blocks; b += 8) acc[0] += p[(size_t)b * B.P];
+        s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     } else if (i < B.P + 8) {
-        float s = 0.0f;
-        for (int b = 0; b < B.blocks; b++) s += B.stats[(size_t)b * 8 + (i - B.P)];
-        B.grad[i] = s;
+        for (int b = q; b < B.blocks; b += 8) s += B.stats[(size_t)b * 8 + (i - B.P)];
     }
+    part[q][e] = s;
+    __syncthreads();
+    if (q == 0 && i < B.P + 8)
+        B.grad[i] = ((part[0][e] + part[1][e]) + (part[2][e] + part[3][e])) + ((part[4][e] + part[5][e]) + (part[6][e] + part[7][e]));
 }
 
 // ---- clip_grad_norm_(max_grad_norm) + RMSprop(alpha, eps) step (torch.optim.RMSprop as SB3's A2C configures it: centered = False,

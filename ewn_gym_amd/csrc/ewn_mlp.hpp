@@ -29,8 +29,9 @@ template <int S> struct MlpGeo {
     static constexpr int O_PI = 0, O_VF = BODY, O_AW = 2 * BODY, O_AB = O_AW + MLP_NA * MLP_H, O_VW = O_AB + MLP_NA, O_VB = O_VW + MLP_H;
     static constexpr int P = O_VB + 1;
     // LDS image of ONE net (body + its head) in MFMA A-operand order, in floats
-    static constexpr int L_W1 = 0, L_B1 = L_W1 + 2 * KS1 * 64, L_W2 = L_B1 + 64, L_B2 = L_W2 + 2 * 32 * 64, L_WH = L_B2 + 64, L_BH = L_WH + 32 * 64;
-    static constexpr int L_END = L_BH + 32;
+    // (the head is evaluated on the VALU: [lane half][output, padded to 8][my 32 units in register order], then 8 biases)
+    static constexpr int L_W1 = 0, L_B1 = L_W1 + 2 * KS1 * 64, L_W2 = L_B1 + 64, L_B2 = L_W2 + 2 * 32 * 64, L_WH = L_B2 + 64, L_BH = L_WH + 2 * 8 * 32;
+    static constexpr int L_END = L_BH + 8;
 };
 
 // unit row of a 32x32 MFMA result held in register r of a lane of half h (lane >> 5)
@@ -54,12 +55,12 @@ EWN_DEV void mlp_pack_net(float *L, const float *P, int net, int tid, int nthrea
         const int l = e & 63, ks = (e >> 6) & 31, mt = e >> 11;
         L[G::L_W2 + e] = W2[(mt * 32 + (l & 31)) * MLP_H + mlp_kcol(ks, l >> 5)];
     }
-    for (int e = tid; e < 32 * 64; e += nthreads) {               // the head, padded to 32 rows
-        const int l = e & 63, ks = e >> 6, row = l & 31;
-        L[G::L_WH + e] = row < nout ? Wh[row * MLP_H + mlp_kcol(ks, l >> 5)] : 0.0f;
+    for (int e = tid; e < 2 * 8 * 32; e += nthreads) {            // the head: [half][output][tile * 16 + register] = Wh[output][unit held there]
+        const int q = e & 31, a = (e >> 5) & 7, hh = e >> 8;
+        L[G::L_WH + e] = a < nout ? Wh[a * MLP_H + 32 * (q >> 4) + mlp_row(q & 15, hh)] : 0.0f;
     }
     for (int e = tid; e < MLP_H; e += nthreads) { L[G::L_B1 + e] = b1[e]; L[G::L_B2 + e] = b2[e]; }
-    for (int e = tid; e < 32; e += nthreads) L[G::L_BH + e] = e < nout ? bh[e] : 0.0f;
+    for (int e = tid; e < 8; e += nthreads) L[G::L_BH + e] = e < nout ? bh[e] : 0.0f;
 }
 
 // accumulator initialised with the bias: register r <- b[mlp_row(r, h)]; rows 8g + 4h .. + 3 are one 16-byte read
@@ -87,11 +88,23 @@ EWN_DEV f32x16 mlp_tanh16(f32x16 a)
 #define MLP_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define MLP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+// value of x in the lane of the other half with the same sample (lane ^ 32)
+EWN_DEV float mlp_other_half(float x, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(((lane ^ 32) & 63) << 2, __float_as_int(x)));
+}
+
 // One net's forward pass on a tile of 32 samples.  L: the net's LDS image; xb(s) = this lane's B operand of layer-1 k-step s,
-// i.e. feature 2 s + (lane >> 5) of sample lane & 31.  Outputs in MFMA layout: h1 / h2 [tile][register] (tanh applied),
-// out = the head tile (row a of sample j in register a & 3 ... of lane (j, half): mlp_row).
-template <int S, class XB>
-EWN_DEV void mlp_forward(const float *L, int lane, XB xb, f32x16 (&h1)[2], f32x16 (&h2)[2], f32x16 &out)
+// i.e. feature 2 s + (lane >> 5) of sample lane & 31.  h1 / h2: the activations in MFMA layout [tile][register] (tanh applied).
+// out[a] (a < NOUT): the head's outputs for sample lane & 31, the same numbers in both lane halves.
+//
+// The two bodies' 64-wide layers are MFMA chains (two independent accumulator tiles, alternating).  The head -- 5 or 1 rows -- is
+// NOT: as a 32-row MFMA tile it cost 32 instructions x 64 cycles for 5/32 (1/32) useful rows, a quarter of the forward pass; on the
+// VALU it is NOUT x 32 FMAs per lane on the units the lane already holds plus one exchange between the lane halves.  Measured
+// (tools/mfma_probe.hip): the f32-input MFMA does not overlap with VALU work on its SIMD -- not of its own wave, hardly of the other
+// wave -- so matrix cycles and VALU issue slots simply add up, and every MFMA that computes padding is pure loss.
+template <int S, int NOUT, class XB>
+EWN_DEV void mlp_forward(const float *L, int lane, XB xb, f32x16 (&h1)[2], f32x16 (&h2)[2], float (&out)[NOUT])
 {
     using G = MlpGeo<S>;
     const int h = lane >> 5;
@@ -113,17 +126,23 @@ EWN_DEV void mlp_forward(const float *L, int lane, XB xb, f32x16 (&h1)[2], f32x1
         if ((ks & 7) == 7) MLP_SCHED_FENCE();
     }
     h2[0] = mlp_tanh16(c0); h2[1] = mlp_tanh16(c1);
-    f32x16 o = mlp_bias_acc(L + G::L_BH, h);
+    // the head on the VALU: my half's 32 units, then the other half's partial sum
+    const float *wh = L + G::L_WH + h * 8 * 32;
     #pragma unroll
-    for (int ks = 0; ks < 32; ks++) {
-        o = MLP_MFMA(L[G::L_WH + ks * 64 + lane], h2[ks >> 4][ks & 15], o);
-        if ((ks & 15) == 15) MLP_SCHED_FENCE();
+    for (int a = 0; a < NOUT; a++) {
+        float acc = 0.0f;
+        #pragma unroll
+        for (int q4 = 0; q4 < 8; q4++) {
+            const float4 w = *(const float4 *)(wh + a * 32 + 4 * q4);
+            const int mt = q4 >> 2, r = (4 * q4) & 15;
+            acc = fmaf(w.x, h2[mt][r], acc); acc = fmaf(w.y, h2[mt][r + 1], acc); acc = fmaf(w.z, h2[mt][r + 2], acc); acc = fmaf(w.w, h2[mt][r + 3], acc);
+        }
+        out[a] = acc;
     }
-    out = o;
+    #pragma unroll
+    for (int a = 0; a < NOUT; a++) {
+        const float o = mlp_other_half(out[a], lane);
+        out[a] = (h ? o + out[a] : out[a] + o) + L[G::L_BH + a];   // half 0's sum first, in both halves: bit-identical results
+    }
 }
 
-// value of x in the lane of the other half with the same sample (lane ^ 32)
-EWN_DEV float mlp_other_half(float x, int lane)
-{
-    return __int_as_float(__builtin_amdgcn_ds_bpermute(((lane ^ 32) & 63) << 2, __float_as_int(x)));
-}

@@ -68,6 +68,8 @@ int ewn_step_k_policy(const ewn_config *cfg, const ewn_state *st, int K, const e
     pc.N = k.N; pc.autoreset = k.autoreset; pc.lane_offset = k.lane_offset; pc.depth = k.depth; pc.K = K;
     pc.shaped = k.shaped; pc.refresh = k.refresh; pc.deterministic = pol->deterministic ? 1 : 0; pc.want_value = pol->value ? 1 : 0;
     pc.rec0 = pol->record_initial_obs ? 1 : 0;
+    static const int stagger = [] { const char *e = getenv("EWN_POLICY_STAGGER"); return e ? atoi(e) : 0; }();   // tuning knob; measured: no effect (the f32 MFMA does not overlap with the other wave's VALU work)
+    pc.stagger = stagger;
     pc.seed_stride = k.seed_stride; pc.W = k.W; pc.reward = k.reward; pc.illegal_reward = k.illegal_reward;
     pc.key = k.key; pc.noise_key = pol->noise_key;
     PolBuf pb;
@@ -130,7 +132,7 @@ static int a2c_grad_launch(const A2cCfg &ac, A2cBuf ab, float *grad, hipStream_t
     kv<<<blocks, NWV * 64, lds, s>>>(ac, ab);    // value pass first: it leaves the advantages for the policy pass
     kp<<<blocks, NWV * 64, lds, s>>>(ac, ab);
     A2cRedBuf rb = { ab.partial, ab.stats, grad, blocks, MlpGeo<S>::P };
-    k_a2c_reduce<<<(MlpGeo<S>::P + 8 + 255) / 256, 256, 0, s>>>(rb);
+    k_a2c_reduce<<<(MlpGeo<S>::P + 8 + A2C_RED_E - 1) / A2C_RED_E, 256, 0, s>>>(rb);
     return launch_status();
 }
 

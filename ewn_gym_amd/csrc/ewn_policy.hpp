@@ -15,6 +15,7 @@
 
 struct PolCfg {
     int N, autoreset, lane_offset, depth, K;
+    int stagger;                                            // start delay of every other wave, in units of 64 cycles (0: none)
     int shaped, refresh, deterministic, want_value, rec0;   // rec0: record row 0 = the observation before step 0 (then K + 1 rows)
     u32 seed_stride, W;
     double reward, illegal_reward;
@@ -111,6 +112,10 @@ __global__ __launch_bounds__(NT, NT / 256) void k_rollout_mlp(PolCfg c, PolBuf B
     if (B.t_rec && c.rec0 && live) rec_store<S, T>(slot, sub, dice, 0, 0, 0, 0, 0, B.t_rec + (size_t)game * STR);
     double ret_acc = 0.0;
     int n_steps = 0, n_eps = 0, n_wins = 0;
+    // The two waves that share a SIMD run the same loop; started together they stay in phase -- both in the network (the matrix
+    // pipe contended, the VALU idle), then both in the search (the reverse).  The block's second half of waves starts c.stagger x 64 cycles late, about
+    // one network evaluation, so that one wave's MFMAs run under the other's search from then on (nothing in the loop re-aligns them).
+    if (wave >= NW / 2 && c.stagger > 0) { for (int i = 0; i < c.stagger; i += 127) __builtin_amdgcn_s_sleep(127); }   // waves w and w + NW / 2 share a SIMD
 
     #pragma unroll 1
     for (int kstep = 0; kstep < c.K; kstep++) {
@@ -141,18 +146,17 @@ __global__ __launch_bounds__(NT, NT / 256) void k_rollout_mlp(PolCfg c, PolBuf B
             for (int d = 0; d < 7; d++) Xs[(CELLS + d) * 32 + jw] = (d == dice - 1) ? 1.0f : 0.0f;
         }
         __builtin_amdgcn_wave_barrier();
-        // ---- the network(s) on the matrix cores: this wave's 32 games are the 32 columns of the tile
-        f32x16 out;
+        // ---- the network(s): this wave's 32 games are the 32 columns of the MFMA tiles; every lane ends up with its column's outputs
         {
             f32x16 h1[2], h2[2];
+            float lo[MLP_NA];
             const float *xcol = Xs + (lane >> 5) * 32 + (lane & 31);
-            mlp_forward<S>(Wpi, lane, [&](int st) { return xcol[st * 64]; }, h1, h2, out);
-            if (lane < 32) *(float4 *)(LX + lane * 8) = make_float4(out[0], out[1], out[2], out[3]);
-            else LX[(lane & 31) * 8 + 4] = out[0];
+            mlp_forward<S, MLP_NA>(Wpi, lane, [&](int st) { return xcol[st * 64]; }, h1, h2, lo);
+            if (lane < 32) { *(float4 *)(LX + lane * 8) = make_float4(lo[0], lo[1], lo[2], lo[3]); LX[lane * 8 + 4] = lo[4]; }
             if (c.want_value) {
-                f32x16 outv;
-                mlp_forward<S>(Wvf, lane, [&](int st) { return xcol[st * 64]; }, h1, h2, outv);
-                if (lane < 32) LX[lane * 8 + 5] = outv[0];
+                float vo[1];
+                mlp_forward<S, 1>(Wvf, lane, [&](int st) { return xcol[st * 64]; }, h1, h2, vo);
+                if (lane < 32) LX[lane * 8 + 5] = vo[0];
             }
         }
         __builtin_amdgcn_wave_barrier();

@@ -1,0 +1,111 @@
+// mfma_probe.hip -- what a wave can issue under a running v_mfma_f32_32x32x2_f32 on gfx950 (measurement tool, not product code;
+// tools/mfma_probe.py drives it).  The fused A2C gradient kernels run one wave per SIMD and interleave MFMA chains with VALU / LDS
+// work: this measures cycles per MFMA for a dependent chain, for two interleaved chains, and with N independent VALU or LDS-read
+// "filler" instructions behind every MFMA, at one and two waves per SIMD.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include <algorithm>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned long long u64;
+
+#define MF(acc) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#define VF(x) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x) : "v"(a))
+#define LR(x) asm volatile("ds_read_b32 %0, %1" : "=v"(x) : "v"(ldsaddr))
+#define VI(x) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x) : "v"(a))
+#define VE(x) asm volatile("v_exp_f32 %0, %0" : "+v"(x))
+#define VC(x) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(a) : "vcc")
+
+template <int MODE, int NF>
+__global__ void probe(float *out, u64 *cyc, int reps)
+{
+    __shared__ float sm[4096];
+    f32x16 c0, c1;
+    for (int i = 0; i < 16; i++) { c0[i] = 0.0f; c1[i] = 1.0f; }
+    float a = 1.0f + threadIdx.x * 1e-9f, b = 0.5f;
+    float f[16];
+    for (int i = 0; i < 16; i++) f[i] = (float)i;
+    sm[threadIdx.x] = 1.0f;
+    __syncthreads();
+    const unsigned ldsaddr = (threadIdx.x & 63) * 4;
+    u64 t0, t1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
+    for (int r = 0; r < reps; r++) {
+        #pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (MODE == 0) MF(c0);                           // one dependent chain
+            if (MODE == 1) { if (k & 1) MF(c1); else MF(c0); } // two chains, alternating
+            if (MODE == 2) { MF(c0); }                       // chain + VALU fillers
+            if (MODE == 3) { if (k & 1) MF(c1); else MF(c0); }
+            if (MODE == 4) { }                               // fillers only
+            if (MODE == 5) { MF(c0); }                       // chain + LDS-read fillers
+            if (MODE == 2 || MODE == 3 || MODE == 4) {
+                #pragma unroll
+                for (int i = 0; i < NF; i++) VF(f[i & 15]);
+            }
+            if (MODE == 5) {
+                #pragma unroll
+                for (int i = 0; i < NF; i++) LR(f[i & 15]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            if (MODE == 6 || MODE == 7) { if (MODE == 6) MF(c0); _Pragma("unroll") for (int i = 0; i < NF; i++) VI(f[i & 15]); }   // integer VALU fillers
+            if (MODE == 8 || MODE == 9) { if (MODE == 8) MF(c0); _Pragma("unroll") for (int i = 0; i < NF; i++) VE(f[i & 15]); }   // transcendental fillers
+            if (MODE == 10) { MF(c0); _Pragma("unroll") for (int i = 0; i < NF; i++) VC(f[i & 15]); }
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15");
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
+    float s = 0.0f;
+    for (int i = 0; i < 16; i++) s += c0[i] + c1[i] + f[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int MODE, int NF>
+static void run(const char *name, int waves_per_simd, int reps, float *out, u64 *cyc)
+{
+    const int threads = 256 * waves_per_simd, blocks = 256;   // one block per CU
+    probe<MODE, NF><<<blocks, threads>>>(out, cyc, 10);
+    hipDeviceSynchronize();
+    probe<MODE, NF><<<blocks, threads>>>(out, cyc, reps);
+    hipDeviceSynchronize();
+    std::vector<u64> h(blocks * threads / 64);
+    hipMemcpy(h.data(), cyc, h.size() * sizeof(u64), hipMemcpyDeviceToHost);
+    std::sort(h.begin(), h.end());
+    const double med = (double)h[h.size() / 2];
+    // s_memtime ticks at 100 MHz on gfx9 (constant clock): report ticks per 8-MFMA group and ns
+    printf("%-34s waves/SIMD %d  NF %2d : %.3f ticks per group of 8 (median wave), = %.1f ns per MFMA slot\n", name, waves_per_simd, NF,
+           med / reps, med / reps / 8.0 * 10.0);
+}
+
+int main(int argc, char **argv)
+{
+    const int reps = argc > 1 ? atoi(argv[1]) : 2000;
+    float *out; u64 *cyc;
+    hipMalloc(&out, 256 * 512 * sizeof(float));
+    hipMalloc(&cyc, 256 * 8 * sizeof(u64));
+    for (int w = 1; w <= 2; w++) {
+        run<0, 0>("dependent chain", w, reps, out, cyc);
+        run<1, 0>("two alternating chains", w, reps, out, cyc);
+        run<2, 4>("chain + 4 VALU behind each", w, reps, out, cyc);
+        run<2, 8>("chain + 8 VALU", w, reps, out, cyc);
+        run<2, 12>("chain + 12 VALU", w, reps, out, cyc);
+        run<2, 16>("chain + 16 VALU", w, reps, out, cyc);
+        run<3, 8>("two chains + 8 VALU", w, reps, out, cyc);
+        run<3, 12>("two chains + 12 VALU", w, reps, out, cyc);
+        run<4, 8>("8 VALU only (no MFMA)", w, reps, out, cyc);
+        run<4, 16>("16 VALU only", w, reps, out, cyc);
+        run<6, 8>("chain + 8 v_and_b32", w, reps, out, cyc);
+        run<6, 12>("chain + 12 v_and_b32", w, reps, out, cyc);
+        run<7, 8>("8 v_and_b32 only", w, reps, out, cyc);
+        run<8, 4>("chain + 4 v_exp_f32", w, reps, out, cyc);
+        run<9, 4>("4 v_exp_f32 only", w, reps, out, cyc);
+        run<10, 8>("chain + 8 v_cndmask", w, reps, out, cyc);
+        run<5, 2>("chain + 2 ds_read_b32 + wait", w, reps, out, cyc);
+        run<5, 4>("chain + 4 ds_read_b32 + wait", w, reps, out, cyc);
+    }
+    return 0;
+}
