@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--spin-ms", type=float, default=6.0,
                     help="approximate length of that clock warm-up (measured on the driver's 20-step shape, five runs each: 6 ms 6.06-6.18 G steps/s, "
                          "30 ms 5.3-6.1, 100 ms 5.6-6.0, 250 ms 2.9-5.5 -- after a long eager queue the single graph launch starts late)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="run the N>1 code path (process group, barrier, MAX / ones / digest all-reduces) even at WORLD_SIZE=1: "
+                         "exercises the RCCL branch on a one-GPU box")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra measurements (single-step launch, no-trajectory rollout, uniform6 agent)")
     return ap.parse_args()
 
@@ -321,8 +324,12 @@ def main():
     cpub = None
     if not args.no_cpu_baseline and world == 1:
         cpub = cpu_baseline(args, args.cpu_baseline_seconds)
-    if world > 1:
+    dist_on = world > 1 or args.force_collectives
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dev = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(dev)
         if args.backend == "nccl":
@@ -348,7 +355,7 @@ def main():
         return env
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -375,9 +382,9 @@ def main():
         spin_steps = max(1, min(100000, int(args.spin_ms * 1e-3 / est)))
         spin = lambda: scratch.launch(spin_steps)   # noqa: E731
     dt, ev_ms = runner.run(args.steps, barrier, use_graph=not args.no_graph, spin=spin)   # exactly K timed steps
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if (world > 1 and args.backend == "nccl") else "cpu")
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if (dist_on and args.backend == "nccl") else "cpu")
     ranks_seen = None
-    if world > 1:
+    if dist_on:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         one = torch.ones(1, dtype=torch.int32, device=tmax.device)
         dist.all_reduce(one, op=dist.ReduceOp.SUM)               # every rank of the process group took part
@@ -385,7 +392,7 @@ def main():
     dt = float(tmax.item())
     # a digest of the final state: the same lanes give the same digest however they are sharded (tests compare it)
     digest = int((env.board.to(torch.int64).reshape(N, -1) * torch.arange(1, args.board_size ** 2 + 1, device="cuda")).sum().item())
-    if world > 1:
+    if dist_on:
         dg = torch.tensor([digest], dtype=torch.int64, device=tmax.device)
         dist.all_reduce(dg, op=dist.ReduceOp.SUM)
         digest = int(dg.item())
@@ -479,13 +486,13 @@ def main():
                        "clock_warmup": None if args.no_spin else "a scratch env of the same configuration stepped ~%g ms right before the timed region (untimed, other state)" % args.spin_ms,
                        "parallelism": "lanes sharded across %d GPU(s), no data-path collective" % world},
             "rccl_ranks": ranks_seen if args.backend == "nccl" else None,
-            "collective": {"backend": args.backend if world > 1 else None, "ranks": ranks_seen},
+            "collective": {"backend": args.backend if dist_on else None, "ranks": ranks_seen},
             "state_digest": digest,
             "extras": extras or None,
             "roofline": roof, "cpu_baseline": cpub,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

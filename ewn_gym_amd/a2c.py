@@ -137,10 +137,11 @@ def n_step_returns(rewards, values, dones, last_value, gamma=0.99, gae_lambda=1.
     return adv, adv + values
 
 
-def all_reduce_gradients(params, world_size=None):
-    """ONE collective per update: flatten every gradient into a single bucket, all-reduce (sum), divide, scatter back."""
+def all_reduce_gradients(params, world_size=None, force=False):
+    """ONE collective per update: flatten every gradient into a single bucket, all-reduce (sum), divide, scatter back.
+    force: issue the collective even in a one-rank group (exercises the RCCL path on a one-GPU box)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return
     grads = [p.grad for p in params if p.grad is not None]
     flat = torch.cat([g.reshape(-1) for g in grads])
@@ -327,6 +328,7 @@ class FusedA2CTrainer:
         self.noise_key = (0 if seed is None else int(seed)) * 0x9E3779B97F4A7C15 & 0xFFFFFFFFFFFFFFFF
         self.gen = torch.Generator(device=self.device)                # policy_fn's sampling only (evaluation is deterministic)
         self.gen.manual_seed(0 if seed is None else int(seed))
+        self.force_collective = False     # tools/nccl_selftest.py: all-reduce the gradient even in a one-rank group
         self.use_graph = use_graph and world == 1
         self._graph = None
         self._warm = False
@@ -340,7 +342,7 @@ class FusedA2CTrainer:
         env.rollout_policy(self.n_steps, self.params, traj=self.traj, noise_key=self.noise_key)
         check(self.lib.ewn_a2c_grad(C.byref(env.cfg), self.n_steps, _ptr(self.traj["record"]), _ptr(self.traj["reward"]), _ptr(self.params),
                                     C.byref(self.hyper), _ptr(self.grad), _ptr(self.scratch), _stream()), "ewn_a2c_grad")
-        if self.world > 1:   # the one collective of the training path: the flat gradient (52 KB), summed; apply divides by the world size
+        if self.world > 1 or self.force_collective:   # the one collective of the training path: the flat gradient (52 KB), summed; apply divides by the world size
             import torch.distributed as dist
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
         check(self.lib.ewn_a2c_apply(C.byref(env.cfg), _ptr(self.params), _ptr(self.sq_avg), _ptr(self.grad), C.byref(self.hyper),

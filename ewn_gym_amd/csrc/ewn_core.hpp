@@ -329,9 +329,23 @@ EWN_DEV double evaluate(const Geom &g, const GState<NW> &s, int heur)
 // 'sim_winrate' heuristic (random playouts, envs/minimax_ewn.py:215-238) brings its own functor (ewn_kernels.hip: SimLeaf).
 template <int NW>
 struct EvalLeaf {
+    static constexpr bool outline_deep = false;
     int heur;
     EWN_DEV double operator()(const Geom &g, const GState<NW> &s) { return evaluate<NW>(g, s, heur); }
 };
+
+template <int NW, int DEPTH, int KIND, bool ROOT, class Leaf>
+__device__ double search(const Geom &g, const GState<NW> &s, int dice, double alpha, double beta, Leaf &leaf, int &bflag, int &bdir);
+
+// A leaf type with a large body (SimLeaf: a playout loop) asks for the depth-4 subtree of a deeper search to be a real function:
+// for_each_legal unrolls its two cube slots, so every level inlined doubles the code below it, and at max_depth 5 / 6 the optimiser
+// gives the unrolling up half way (with a warning per loop).  One call per subtree costs nothing next to 1 296 leaves x 100 playouts.
+template <int NW, int DEPTH, int KIND, class Leaf>
+__device__ __attribute__((noinline)) double search_outlined(const Geom &g, const GState<NW> &s, int dice, double alpha, double beta, Leaf &leaf)
+{
+    int f = 0, d = 0;
+    return search<NW, DEPTH, KIND, false>(g, s, dice, alpha, beta, leaf, f, d);
+}
 
 template <int NW, int DEPTH, int KIND, bool ROOT, class Leaf>
 __device__ double search(const Geom &g, const GState<NW> &s, int dice, double alpha, double beta, Leaf &leaf, int &bflag, int &bdir)
@@ -343,7 +357,9 @@ __device__ double search(const Geom &g, const GState<NW> &s, int dice, double al
         if constexpr (KIND >= 2) {
             double expected = 0.0;
             for (int d = 1; d <= 6; d++) {
-                const double v = search<NW, DEPTH - 1, (KIND == 2 ? 1 : 0), false>(g, s, d, alpha, beta, leaf, bflag, bdir);
+                double v;
+                if constexpr (Leaf::outline_deep && DEPTH - 1 == 4) v = search_outlined<NW, DEPTH - 1, (KIND == 2 ? 1 : 0)>(g, s, d, alpha, beta, leaf);
+                else v = search<NW, DEPTH - 1, (KIND == 2 ? 1 : 0), false>(g, s, d, alpha, beta, leaf, bflag, bdir);
                 expected = expected + v / 6.0;
             }
             return expected;
@@ -353,7 +369,9 @@ __device__ double search(const Geom &g, const GState<NW> &s, int dice, double al
             for_each_legal<SIDE, NW>(g, s, dice, [&](int flag, int k, int dir) -> bool {
                 GState<NW> c = s;
                 apply_move<SIDE, NW>(g, c, k, dir);
-                const double v = search<NW, DEPTH - 1, (SIDE == 0 ? 2 : 3), false>(g, c, dice, alpha, beta, leaf, bflag, bdir);
+                double v;
+                if constexpr (Leaf::outline_deep && DEPTH - 1 == 4) v = search_outlined<NW, DEPTH - 1, (SIDE == 0 ? 2 : 3)>(g, c, dice, alpha, beta, leaf);
+                else v = search<NW, DEPTH - 1, (SIDE == 0 ? 2 : 3), false>(g, c, dice, alpha, beta, leaf, bflag, bdir);
                 if constexpr (SIDE == 0) {
                     if (v > best) { best = v; if constexpr (ROOT) { bflag = flag; bdir = dir; } }
                     if (best > alpha) alpha = best;

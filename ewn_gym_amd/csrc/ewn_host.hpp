@@ -174,9 +174,9 @@ int ewn_launch_step_d3_h2(const ewn_config *cfg, const Geom &g, const KCfg &k, c
 // ewn_rollout_s<S>.hip: K env steps per launch (ewn_rollout.hpp), one unit per board size
 struct RollCfg;
 struct RollBuf;
-int ewn_launch_rollout_s5(const RollCfg &rc, const RollBuf &rb, int T, int opp, int rngk, int agent, hipStream_t s);
-int ewn_launch_rollout_s6(const RollCfg &rc, const RollBuf &rb, int T, int opp, int rngk, int agent, hipStream_t s);
-int ewn_launch_rollout_s7(const RollCfg &rc, const RollBuf &rb, int T, int opp, int rngk, int agent, hipStream_t s);
-int ewn_launch_rollout_s8(const RollCfg &rc, const RollBuf &rb, int T, int opp, int rngk, int agent, hipStream_t s);
+int ewn_launch_rollout_s5(const RollCfg &rc, const RollBuf &rb, int T, int opp, int rngk, int agent, bool h2, hipStream_t s);
+int ewn_launch_rollout_s6(const RollCfg &rc, const RollBuf &rb, int T, int opp, int rngk, int agent, bool h2, hipStream_t s);
+int ewn_launch_rollout_s7(const RollCfg &rc, const RollBuf &rb, int T, int opp, int rngk, int agent, bool h2, hipStream_t s);
+int ewn_launch_rollout_s8(const RollCfg &rc, const RollBuf &rb, int T, int opp, int rngk, int agent, bool h2, hipStream_t s);
 // ewn_policy.hip: the policy-driven rollout (ewn_step_k_policy); EWN_OK when it serves the configuration
 int ewn_policy_supported(const ewn_config *cfg, const Geom &g);

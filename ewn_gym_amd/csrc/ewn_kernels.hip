@@ -563,6 +563,7 @@ EWN_DEV void rollout_ply(const Geom &g, GState<NW> &s, PlayoutRng &ps)
 // `random`); bit-exact with oracle/ewn_oracle.c, which mirrors it.
 template <int NW>
 struct SimLeaf {
+    static constexpr bool outline_deep = true;   // ewn_core.hpp search_outlined
     PlayoutRng ps;
     int cur;      // 0 TOP_LEFT, 1 BOTTOM_RIGHT: MinimaxEnv.current_player
     int nsims;
@@ -725,6 +726,10 @@ static int launch_minimax_sim(const Geom &g, int M, const int8_t *boards, const 
     case 2: k_predict_minimax_sim<NW, 2><<<grid, 64, 0, s>>>(g, M, boards, dice, active, obs_id, key, EWN_SIM_WINRATE_PLAYOUTS, actions, values); break;
     case 3: k_predict_minimax_sim<NW, 3><<<grid, 64, 0, s>>>(g, M, boards, dice, active, obs_id, key, EWN_SIM_WINRATE_PLAYOUTS, actions, values); break;
     case 4: k_predict_minimax_sim<NW, 4><<<grid, 64, 0, s>>>(g, M, boards, dice, active, obs_id, key, EWN_SIM_WINRATE_PLAYOUTS, actions, values); break;
+    // max_depth 5 / 6: thousands of leaves x 100 playouts per observation, one thread each -- seconds per launch (the reference: minutes
+    // per move); served because the reference has no such limit (classical_policies/minimax.py:19-73 with envs/minimax_ewn.py:36-37)
+    case 5: k_predict_minimax_sim<NW, 5><<<grid, 64, 0, s>>>(g, M, boards, dice, active, obs_id, key, EWN_SIM_WINRATE_PLAYOUTS, actions, values); break;
+    case 6: k_predict_minimax_sim<NW, 6><<<grid, 64, 0, s>>>(g, M, boards, dice, active, obs_id, key, EWN_SIM_WINRATE_PLAYOUTS, actions, values); break;
     default: return EWN_EUNSUPPORTED;
     }
     return launch_status();
@@ -937,8 +942,10 @@ static int rollout_plan(const ewn_config *cfg, const Geom &g, const KCfg &k, int
 {
     if (fast_tables_bytes(g.S, g.L) <= 0 || cfg->shaped) return EWN_EUNSUPPORTED;
     if (cfg->opponent_kind == EWN_OPP_RANDOM) opp = 1;
-    else if (cfg->opponent_kind == EWN_OPP_MINIMAX && fast_heur_lean(cfg->heuristic)) opp = cfg->max_depth > 4 ? 2 : 0;
+    else if (cfg->opponent_kind == EWN_OPP_MINIMAX && fast_heur_step(cfg->heuristic)) opp = cfg->max_depth > 4 ? 2 : 0;
     else return EWN_EUNSUPPORTED;
+    const bool h2 = cfg->opponent_kind == EWN_OPP_MINIMAX && cfg->heuristic == EWN_H_TWO_MIN_DIST;   // its own kernel instances, RandomAgent / sample agents
+    if (h2 && agent_kind == EWN_AGENT_MINIMAX) return EWN_EUNSUPPORTED;
     if (agent_kind == EWN_AGENT_RANDOM || agent_kind == EWN_AGENT_SAMPLE) agent = 0;
     else if (agent_kind == EWN_AGENT_MINIMAX) {
         if (agent_max_depth < 1) return EWN_EINVAL;
@@ -951,7 +958,7 @@ static int rollout_plan(const ewn_config *cfg, const Geom &g, const KCfg &k, int
     const bool mt = cfg->rng_kind == EWN_RNG_MT19937;
     if (agent != 0) T = 2;
     else if (opp == 1) T = 1;
-    else if (opp == 2) T = mt ? 2 : (k.N <= 131072 ? 2 : 1);
+    else if (opp == 2) T = h2 ? 1 : (mt ? 2 : (k.N <= 131072 ? 2 : 1));   // 'two_min_dist' at max_depth 5 / 6: the reference's loops, one lane per game
     else T = mt ? 1 : rollout_threads_per_game(k.N);
     return EWN_OK;
 }
@@ -1011,11 +1018,12 @@ int ewn_step_k(const ewn_config *cfg, const ewn_state *st, int K, int agent_kind
         rb.t_rec = out->record;
     }
     hipStream_t s = (hipStream_t)stream;
+    const bool h2 = opp != 1 && cfg->heuristic == EWN_H_TWO_MIN_DIST;
     switch (g.S) {
-    case 5: return ewn_launch_rollout_s5(rcf, rb, T, opp, k.rng_kind, agent, s);
-    case 6: return ewn_launch_rollout_s6(rcf, rb, T, opp, k.rng_kind, agent, s);
-    case 7: return ewn_launch_rollout_s7(rcf, rb, T, opp, k.rng_kind, agent, s);
-    default: return ewn_launch_rollout_s8(rcf, rb, T, opp, k.rng_kind, agent, s);
+    case 5: return ewn_launch_rollout_s5(rcf, rb, T, opp, k.rng_kind, agent, h2, s);
+    case 6: return ewn_launch_rollout_s6(rcf, rb, T, opp, k.rng_kind, agent, h2, s);
+    case 7: return ewn_launch_rollout_s7(rcf, rb, T, opp, k.rng_kind, agent, h2, s);
+    default: return ewn_launch_rollout_s8(rcf, rb, T, opp, k.rng_kind, agent, h2, s);
     }
 }
 

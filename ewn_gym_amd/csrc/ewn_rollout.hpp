@@ -202,7 +202,9 @@ EWN_DEV void roll_opponent_half(const FastTab<S> *Tb, RState<S> &s, u32 e, int o
 
 // AGENT 0: RandomAgent (the hash-driven uniform legal pick of ewn_step_out.random_action); 1: ExpectiMinimaxAgent of
 // max_depth 1-4 ('hybrid'); 2: of max_depth 5-6.  OPP as in k_step_d3: 0 minimax max_depth 1-4, 1 RandomAgent, 2 minimax 5-6.
-template <int S, int T, int OPP, int RNGK, int AGENT>
+// H2: the opponent's search runs on the 'two_min_dist' table image (envs/minimax_ewn.py:133-178; a side's index is the sum of its two
+// smallest distances, ewn_fast.hpp): RandomAgent / sample agents only
+template <int S, int T, int OPP, int RNGK, int AGENT, bool H2 = false>
 __global__ __launch_bounds__(D3_BS, ((OPP == 2 || AGENT == 2) ? 2 : 1)) void k_rollout_d3(RollCfg c, RollBuf B) // the max_depth 5 / 6 search: hold it to 256 registers (two waves per SIMD)
 {
     constexpr int CELLS = S * S, GPB = D3_BS / T; // games per block
@@ -285,8 +287,8 @@ __global__ __launch_bounds__(D3_BS, ((OPP == 2 || AGENT == 2) ? 2 : 1)) void k_r
         RSTAMP(1); // agent half
         // the opponent's search: run by every lane (lanes without a pending reply compute on a harmless state)
         int oflag = 0, odir = 0;
-        if constexpr (OPP == 0) d3_search<S, T>(Tb, s, dice, sub, c.depth, oflag, odir);
-        if constexpr (OPP == 2) d5_dispatch<S, TS>(Tb, s, dice, T > 2 ? (sub & 1) : sub, oflag, odir);
+        if constexpr (OPP == 0) d3_search<S, T, H2>(Tb, s, dice, sub, c.depth, oflag, odir);
+        if constexpr (OPP == 2) d5_dispatch<S, TS, H2>(Tb, s, dice, T > 2 ? (sub & 1) : sub, oflag, odir);
         RSTAMP(2); // search
         if (reply) {
             // opponent half, envs/ewn.py:464-486
@@ -391,10 +393,11 @@ __global__ __launch_bounds__(D3_BS, ((OPP == 2 || AGENT == 2) ? 2 : 1)) void k_r
 // launch and writes row k of the trajectory when it finishes its step k -- results are identical to k_rollout_d3's, bit for bit
 // (tests/test_gpu_rollout.py).  A wave leaves the loop when its last game is done: ~K (1 + p) + 2 sqrt(K p (1 - p)) iterations
 // for p = the share of two-cube decisions, against K iterations of twice the search length.
-template <int S, int T, int OPP, int RNGK>
+template <int S, int T, int OPP, int RNGK, bool H2 = false>
 __global__ __launch_bounds__(D3_BS, (OPP == 2 ? 2 : 1)) void k_rollout_slots(RollCfg c, RollBuf B)
 {
     static_assert(OPP == 0 || OPP == 2, "minimax opponents");
+    static_assert(!(H2 && OPP == 2), "'two_min_dist' at max_depth 5 / 6 keeps the reference's loops (d5_search): lock-step kernel only");
     constexpr int CELLS = S * S, GPB = D3_BS / T;   // games per block
     constexpr int TS = T > 2 ? 2 : T;               // lanes per game the depth-5 search can use
     constexpr int STR = RecGeo<S>::STR;             // LDS bytes per game: the game's board slot, one trajectory record wide
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(D3_BS, (OPP == 2 ? 2 : 1)) void k_rollout_slots(Rol
         // one cube's three roots of the opponent's search, run by every lane (lanes without a pending reply compute on a harmless
         // state, so the DPP exchanges inside always see their partners)
         bool second = false;
-        if constexpr (OPP == 0) best = d3_search<S, T, false, true>(Tb, s, dice, sub, c.depth, oflag, odir, phase, best, &second);
+        if constexpr (OPP == 0) best = d3_search<S, T, H2, true>(Tb, s, dice, sub, c.depth, oflag, odir, phase, best, &second);
         else best = d5c_search<S, TS, true>(Tb, s, dice, T > 2 ? (sub & 1) : sub, oflag, odir, phase, best, &second);
         if (pending && phase == 0 && reply && second) phase = 1; // the same env step goes on with the second cube
         else if (pending) {

@@ -688,12 +688,17 @@ __global__ __launch_bounds__(D3_BS, (OPP == 2 ? 2 : 1)) void k_step_d3(D3Cfg c, 
         }
     }
     if constexpr (RNGK == 0) { if (D3_STEP_PRIO) __builtin_amdgcn_s_setprio(D3_STEP_PRIO); }
+    // the terminal-observation staging area exists only when the caller asked for terminal observations (or the block is static):
+    // together with the refill requests going straight to their global list (below), the MT kind's step block then needs 37 KB, four
+    // blocks fit a CU and all 512 step + 512 refill blocks of a 65 536-lane launch are resident at once -- at 44.5 KB three fitted,
+    // 768 of the 1 024, and the launch ran in two rounds (26.6 -> 32.8 us per step between rounds 1 and 2, when the table image grew)
+    const int nboards = (LDS_ST != 0 || B.tboard != nullptr) ? 2 : 1;
     int8_t *lds_t = lds + GPB * CELLS;
-    int8_t *tb = lds + ((2 * GPB * CELLS + 15) & ~15);
+    int8_t *tb = lds + ((nboards * GPB * CELLS + 15) & ~15);
     tables_to_lds<FAST_TAB_BYTES(S)>(tb, (const int8_t *)B.tables); // LDS-DMA, waited for at the barrier
     const FastTab<S> *Tb = (const FastTab<S> *)tb;
     uint8_t *garr = (uint8_t *)(tb + FAST_TAB_BYTES(S));          // 16 bytes per game: d3_decode's scatter area
-    [[maybe_unused]] u32 *qlds = (u32 *)(garr + GPB * 16);        // [0] = requests parked by this block, then up to 2*GPB x uint4
+    [[maybe_unused]] u32 *qlds = (u32 *)(garr + GPB * 16);        // [0] = refill requests parked by this block so far (they go straight to its global list)
     if constexpr (RNGK == 0) { if (B.mtq && threadIdx.x == 0) qlds[0] = 0; }
 
     const int g0 = ((int)blockIdx.x - c.refill_blocks) * GPB, ng = min(GPB, c.N - g0);
@@ -800,9 +805,10 @@ __global__ __launch_bounds__(D3_BS, (OPP == 2 ? 2 : 1)) void k_step_d3(D3Cfg c, 
                 LaneRng::Pending pend; pend.n = 0; pend.slot0 = pend.slot1 = pend.seed0 = pend.seed1 = 0;
                 r.next_episode(B.rng, c.N, game, c.seed_stride, c.key, (RNGK == 0 && B.mtq) ? &pend : nullptr);
                 if constexpr (RNGK == 0) {
-                    if (B.mtq && writer) { // park the refill requests in LDS; the block moves them to its list region below
-                        if (pend.n >= 1u) ((uint4 *)(qlds + 4))[atomicAdd(&qlds[0], 1u)] = make_uint4((u32)game | (pend.slot0 << 30), pend.seed0, epoch, 0u);
-                        if (pend.n >= 2u) ((uint4 *)(qlds + 4))[atomicAdd(&qlds[0], 1u)] = make_uint4((u32)game | (pend.slot1 << 30), pend.seed1, epoch, 0u);
+                    if (B.mtq && writer) { // park the refill requests in this block's own region of this launch's list (<= 2 per game: never full)
+                        uint4 *list = Q.list + ((size_t)phase * Q.nblk + ((int)blockIdx.x - c.refill_blocks)) * Q.per_blk;
+                        if (pend.n >= 1u) list[atomicAdd(&qlds[0], 1u)] = make_uint4((u32)game | (pend.slot0 << 30), pend.seed0, epoch, 0u);
+                        if (pend.n >= 2u) list[atomicAdd(&qlds[0], 1u)] = make_uint4((u32)game | (pend.slot1 << 30), pend.seed1, epoch, 0u);
                     }
                 }
                 d3_init_state<S>(Tb, s);
@@ -846,12 +852,9 @@ __global__ __launch_bounds__(D3_BS, (OPP == 2 ? 2 : 1)) void k_step_d3(D3Cfg c, 
     block_copy_out(B.board + (size_t)g0 * CELLS, lds, ng * CELLS);
     if (B.tboard) block_copy_out(B.tboard + (size_t)g0 * CELLS, lds_t, ng * CELLS);
     if constexpr (RNGK == 0) {
-        if (B.mtq) { // this block's parked requests -> its own region of this launch's list; the count is a plain store
+        if (B.mtq) { // how many requests this block parked: a plain store (the __syncthreads above ordered the LDS counter)
             const int sb = (int)blockIdx.x - c.refill_blocks;
-            const u32 nq = min(qlds[0], (u32)Q.per_blk);
-            uint4 *list = Q.list + ((size_t)phase * Q.nblk + sb) * Q.per_blk;
-            for (u32 i = threadIdx.x; i < nq; i += blockDim.x) list[i] = ((const uint4 *)(qlds + 4))[i];
-            if (threadIdx.x == 0) Q.cnt[(size_t)phase * Q.nb4 + sb] = nq;
+            if (threadIdx.x == 0) Q.cnt[(size_t)phase * Q.nb4 + sb] = min(qlds[0], (u32)Q.per_blk);
         }
     }
 }

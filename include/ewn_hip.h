@@ -42,7 +42,7 @@ extern "C" {
 #define EWN_EINVAL (-1)      /* bad argument / unsupported configuration (the reference asserts, envs/ewn.py:47) */
 #define EWN_ENULL (-2)       /* required pointer is NULL */
 #define EWN_ELAUNCH (-3)     /* kernel launch failed (hipGetLastError != hipSuccess) */
-#define EWN_EUNSUPPORTED (-4)/* valid in the reference, not built here (e.g. board_size > 11, 'sim_winrate' deeper than 4) */
+#define EWN_EUNSUPPORTED (-4)/* valid in the reference, not built here (e.g. board_size > 11, max_depth > 6) */
 
 /* opponent_kind: constants/policy.py:4-10 (uct / alpha_zero are out of scope) */
 #define EWN_OPP_RANDOM 0
@@ -59,9 +59,9 @@ extern "C" {
 #define EWN_H_TWO_MIN_DIST 2
 #define EWN_H_ATTK 3
 #define EWN_H_SIM_WINRATE 4 /* MinimaxEnv.simulate as the search leaf (envs/minimax_ewn.py:36-37, 215-238): 100 random playouts per
-                               leaf; searches only (ewn_evaluate answers it through ewn_playout_wins); max_depth <= 4 */
+                               leaf; searches only (ewn_evaluate answers it through ewn_playout_wins); max_depth 5 / 6 run for seconds */
 #define EWN_SIM_WINRATE_PLAYOUTS 100 /* MinimaxEnv.num_simulations, envs/minimax_ewn.py:20 */
-#define EWN_SIM_WINRATE_MAX_DEPTH 4
+#define EWN_SIM_WINRATE_MAX_DEPTH 6
 
 /* info codes of ewn_step: the messages of envs/ewn.py:448,454,473,478 and envs/training_ewn.py:56 */
 #define EWN_INFO_NONE 0

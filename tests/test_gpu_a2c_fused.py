@@ -61,6 +61,7 @@ def test_fused_gradient_matches_torch_autograd(ea, N, S, K, ent_coef, opp):
     model.zero_grad()
     loss.backward()
     ref = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    pl, vl, en = pl.detach(), vl.detach(), en.detach()
     got = grad[:-8]
     rel = float((got - ref).norm() / ref.norm())
     assert rel < 2e-4, (rel, float(ref.norm()))

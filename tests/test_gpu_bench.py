@@ -43,3 +43,15 @@ def test_short_bench_line_is_self_consistent(prelaunched):
     if r["valu_issue"]:
         assert 0 < r["valu_issue"]["frac"] <= 1.0
     assert abs(b["value"] - b["config"]["lanes_per_gpu"] * b["steps"] / (b["ms_per_step"] * 1e-3 * b["steps"])) / b["value"] < 1e-9
+
+
+def test_rccl_branch_runs_at_world_size_one(prelaunched):
+    """backend nccl (= RCCL) with one rank on the one-GPU box: bench.py's N>1 path (process group with device_id, barrier, the MAX /
+    ones / digest all-reduces on device tensors) and the trainers' flat-gradient all-reduce"""
+    b = _line(prelaunched, "bench_nccl_w1")
+    one = _line(prelaunched, "bench_1rank")
+    assert b["rccl_ranks"] == 1 and b["collective"] == {"backend": "nccl", "ranks": 1}
+    assert b["state_digest"] == one["state_digest"]
+    t = _line(prelaunched, "nccl_selftest")
+    assert t["backend"] == "nccl" and t["world"] == 1 and t["rccl_ranks"] == 1
+    assert t["bucket_ok"] and t["fused_updated"] and t["grad_norm"] > 0

@@ -768,7 +768,7 @@ def test_generic_kernels_stay_covered(ea):
               philox_key=10, check_terminal=False)
 
 
-@pytest.mark.parametrize("S,L,depth,n", [(5, 3, 1, 64), (5, 3, 2, 48), (5, 3, 3, 24), (7, 4, 2, 16), (6, 3, 4, 3)])
+@pytest.mark.parametrize("S,L,depth,n", [(5, 3, 1, 64), (5, 3, 2, 48), (5, 3, 3, 24), (7, 4, 2, 16), (6, 3, 4, 3), (5, 3, 5, 2)])
 def test_sim_winrate_as_a_search_leaf(ea, S, L, depth, n):
     """ExpectiMinimaxAgent(heuristic='sim_winrate') (classical_policies/minimax.py:22-23 -> envs/minimax_ewn.py:36-37, 215-238):
     every leaf is 100 random playouts whose first mover follows the reference's current_player chain.  Bit-exact against the
@@ -785,7 +785,7 @@ def test_sim_winrate_as_a_search_leaf(ea, S, L, depth, n):
     if depth == 1:                                  # value = max over root moves of a playout win rate: multiples of 1/100
         assert np.allclose(v * 100, np.round(v * 100))
     with pytest.raises(ea.EwnError):
-        ea.predict_minimax(b, d, 5, "sim_winrate", cube_layer=L)
+        ea.predict_minimax(b, d, 7, "sim_winrate", cube_layer=L)   # max_depth > 6: not built for any heuristic
 
 
 def test_step_with_sim_winrate_opponent(ea):

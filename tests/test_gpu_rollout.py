@@ -18,6 +18,9 @@ def ea():
     return ewn_gym_amd
 
 
+SLOT_N = 66000   # two lanes per game x 66 000 games >= 131 072 lanes: the launcher picks k_rollout_slots (one root cube per loop iteration)
+
+
 def bits(x):
     return np.ascontiguousarray(x, dtype=np.float64).view(np.uint64)
 
@@ -95,6 +98,21 @@ def test_rollout_integer_heuristic_opponents(ea, heur, depth):
     _rollout_vs_oracle(ea, 700, 100, 500, 6, 2, opponent_policy="minimax", max_depth=depth, heuristic=heur, rng="philox", philox_key=depth)
 
 
+@pytest.mark.parametrize("N,lo,kw", [
+    (700, 100, dict(max_depth=3)), (700, 0, dict(max_depth=2, board_size=7)), (SLOT_N, 30000, dict(max_depth=3)), (SLOT_N, 100, dict(max_depth=4, board_size=6)),
+    (140000, 139000, dict(max_depth=3)), (300, 0, dict(max_depth=5)), (900, 0, dict(max_depth=3, rng="mt19937", autoreset=False)),
+], ids=lambda v: str(v) if not isinstance(v, dict) else "-".join("%s=%s" % kv for kv in sorted(v.items())))
+def test_rollout_two_min_dist_opponent(ea, N, lo, kw):
+    """'two_min_dist' (envs/minimax_ewn.py:133-178) inside the K-step kernels: its table image has its own instances of the lock-step
+    and of the slot-task kernel (max_depth 1-4; max_depth 5 / 6 keep the reference's loops, lock-step, one lane per game)"""
+    kw = dict(kw)
+    rng = kw.pop("rng", "philox")
+    autoreset = kw.pop("autoreset", True)
+    n = 96 if kw["max_depth"] >= 5 else 256
+    _rollout_vs_oracle(ea, N, lo, lo + n, 4 if kw["max_depth"] >= 5 else 7, 2, autoreset=autoreset, opponent_policy="minimax", heuristic="two_min_dist", rng=rng,
+                       philox_key=500 + kw["max_depth"], layout="record" if N == SLOT_N else "columns", **kw)
+
+
 def test_rollout_depth5_opponent(ea):
     _rollout_vs_oracle(ea, 200, 0, 96, 5, 2, opponent_policy="minimax", max_depth=5, rng="philox", philox_key=55)
 
@@ -103,9 +121,6 @@ def test_rollout_depth5_opponent(ea):
 def test_rollout_other_board_sizes(ea, S):
     _rollout_vs_oracle(ea, 1000, 300, 600, 8, 2, board_size=S, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=S)
     _rollout_vs_oracle(ea, 40000, 20000, 20128, 5, 2, board_size=S, opponent_policy="random", rng="philox", philox_key=S + 1, board_column=False)
-
-
-SLOT_N = 66000   # two lanes per game x 66 000 games >= 131 072 lanes: the launcher picks k_rollout_slots (one root cube per loop iteration)
 
 
 @pytest.mark.parametrize("kw", [
