@@ -137,7 +137,7 @@ def test_default_kernel_selection_is_not_changed_by_the_environment():
         assert lanes(entry, opponent_kind=0, n_lanes=65536) == 1          # RandomAgent opponent: one lane per game
         assert lanes(entry, opponent_kind=1, max_depth=5, n_lanes=65536) == 2
         assert lanes(entry, opponent_kind=1, max_depth=5, n_lanes=262144) == 1
-        assert lanes(entry, opponent_kind=1, heuristic=2, n_lanes=65536) == (2 if entry == 0 else 0)   # 'two_min_dist': the fused step kernel has instances for its image, the K-step rollout kernels do not
+        assert lanes(entry, opponent_kind=1, heuristic=2, n_lanes=65536) == 2   # 'two_min_dist': the fused step kernel and (since round 3) the K-step rollout kernels have instances for its image
         assert lanes(entry, opponent_kind=1, board_size=7, cube_layer=4, n_lanes=65536) == 0
     assert lanes(0, opponent_kind=1, shaped=1, n_lanes=65536) == 2 and lanes(1, opponent_kind=1, shaped=1, n_lanes=65536) == 0
     assert lib.ewn_lanes_per_game(C.byref(cfg(n_lanes=0)), 0) == -1
