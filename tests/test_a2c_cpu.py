@@ -62,7 +62,7 @@ def _worker(rank, world, port, q):
     local = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
     all_reduce_gradients(list(m.parameters()))
     red = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
-    q.put((rank, local, red))
+    q.put((rank, local.tolist(), red.tolist()))   # by value: a tensor travels as a shared-memory handle that dies with this process
     dist.barrier()
     dist.destroy_process_group()
 
@@ -76,7 +76,7 @@ def test_single_bucket_gradient_all_reduce_with_two_gloo_ranks():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict((r, (l, g)) for r, l, g in (q.get(timeout=120) for _ in range(2)))
+    res = dict((r, (torch.tensor(l), torch.tensor(g))) for r, l, g in (q.get(timeout=120) for _ in range(2)))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
