@@ -677,6 +677,174 @@ __global__ __launch_bounds__(BS) void k_mcts_rollout_lean(Geom g, int M, int tot
     }
 }
 
+// ---------------------------------------------------------------- K env steps per launch with the flat Monte-Carlo opponent
+//
+// ewn_step with the MCTS opponent is three launches per step (agent half, playouts, opponent half) with the canonical
+// observation, the win counters and the chosen action travelling through scratch memory in between.  Here the three phases are
+// the phases of ONE loop body, K steps per launch: a thread owns a game for the rules (state in registers for the whole launch),
+// and between the two halves of a step the block's 256 lanes regroup into groups of 8..64 lanes that play the playouts of the
+// block's (game, root move) cells out of LDS -- the same generator, the same playout numbering, so the results are those of
+// k_mcts_rollout_lean bit for bit.  Block barriers separate the phases (the games of a block are in lock step).
+EWN_DEV PState pstate_from_gstate(const Geom &g, const GState<1> &c)
+{
+    u32 w[4] = { 0x40404040u, 0x40404040u, 0x40404040u, 0x40404040u };   // every cube off the board (pstate_load's encoding)
+    #pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const u32 cp = (u32)pos_get<1>(c.posP, k), rp = (cp * g.div_magic) >> 16, cn = (u32)pos_get<1>(c.posN, k), rn = (cn * g.div_magic) >> 16;
+        if ((c.aliveP >> k) & 1u) w[k & 1] ^= (0x40u ^ (rp * 8u + (cp - rp * (u32)g.S))) << (8 * (k >> 1));
+        if ((c.aliveN >> k) & 1u) w[2 + (k & 1)] ^= (0x40u ^ (rn * 8u + (cn - rn * (u32)g.S))) << (8 * (k >> 1));
+    }
+    const PState st = { w[0], w[1], w[2], w[3] };
+    return st;
+}
+
+struct MctsRoll { int K, total, gl, agent_sample, strd, gpb; };   // strd: bytes per game of the dynamic LDS area (a record, or S*S)
+
+// mr.gpb games per block of BS threads: the rules run one thread per game (the block's first lanes), the playouts on all BS lanes.
+// Not 256 games per block: the playouts are where the time goes, and 65 536 games at 256 per block are 1 024 waves -- ONE per SIMD,
+// half the VALU issue rate and no latency hiding (measured: 767 us per step at MCTS(10 x 5) against 409 for the three-launch step;
+// 426 at 32 games per block).  The block barriers between the phases are what is left of the difference: the three-launch step
+// balances its playouts over the whole chip, this kernel over one block's cells.
+#define MR_GPB 128        // the most games a block takes (LDS arrays); the launcher picks mr.gpb <= MR_GPB (default 64)
+
+__global__ __launch_bounds__(BS) void k_rollout_mcts(Geom g, KCfg c, KState st, MctsRoll mr, RollBuf B)
+{
+    extern __shared__ __attribute__((aligned(16))) int8_t lds[];   // [MR_GPB][strd]: packed boards in and out, trajectory rows in between
+    __shared__ PlayTab T;
+    __shared__ PState pb0[MR_GPB];
+    __shared__ u32 pword[MR_GPB];
+    __shared__ int8_t pdice[MR_GPB];
+    __shared__ int wins[MR_GPB][6];
+    __shared__ uint16_t livec[MR_GPB * 6];
+    __shared__ int nlive_s, next_slot;
+    __shared__ int nextc[BS / 8], myslot[BS / 8];
+    playtab_build(&T, g.S);
+    const int tid = (int)threadIdx.x, lane0 = (int)blockIdx.x * mr.gpb, nl = min(mr.gpb, c.N - lane0), lane = lane0 + tid;
+    const bool owner = tid < mr.gpb, live = owner && lane < c.N;
+    uint4 hdr = make_uint4(0u, 0u, 0u, 0u);
+    int dice = 1;
+    bool frozen = true;
+    if (live) { hdr = *rng_hdr_ptr(st.rng, lane); dice = st.dice[lane]; frozen = st.done[lane] != 0; }
+    const bool frozen0 = frozen;
+    block_copy_in(lds, st.board + (size_t)lane0 * g.cells, nl * g.cells);
+    __syncthreads();
+    GState<1> s;
+    decode_board<1>(g, lds + (live ? tid : 0) * g.cells, s);
+    LaneRng r; r.load(c.rng_kind, hdr, rng_win_ptr(st.rng, c.N, c.W, live ? lane : 0, RNGF_CUR(hdr.w)), c.W, c.key);
+    r.begin_kernel();
+    double ret_acc = 0.0;
+    int n_steps = 0, n_eps = 0, n_wins = 0;
+    const int tc = 1 << mr.gl, glane = tid & (tc - 1), grp = tid >> mr.gl;
+
+    for (int kstep = 0; kstep < mr.K; kstep++) {
+        const bool active = live && !frozen;
+        StepRes o; o.reward = 0.0; o.term = (live && frozen) ? 1 : 0; o.trunc = 0; o.info = EWN_INFO_NONE;
+        int aflag = 0, adir = 0, n_root = 0;
+        bool reply = false;
+        GState<1> cst = s;
+        if (active) {
+            // the stand-in agent: RandomAgent.predict (the hash pick of ewn_step_out.random_action) or action_space.sample()
+            const u32 w = agent_hash(r.seed_mix(), r.draws(), (u32)(c.lane_offset + lane), c.key);
+            if (mr.agent_sample) { const int a6 = (int)__umulhi(w, 6u); aflag = a6 >= 3 ? 1 : 0; adir = a6 - 3 * aflag; }
+            else {
+                const int n = for_each_legal<0, 1>(g, s, dice, [](int, int, int) { return true; });
+                if (n > 0) {
+                    const int pick = (int)__umulhi(w, (u32)n);
+                    int i = 0;
+                    for_each_legal<0, 1>(g, s, dice, [&](int flag, int, int dir) { if (i == pick) { aflag = flag; adir = dir; } i++; return i <= pick; });
+                }
+            }
+            r.prefetch();
+            r.begin_step();
+            reply = step_agent<1>(g, c, s, dice, aflag, adir, r, nullptr, o);      // envs/ewn.py:438-458
+            if (reply) { // MctsAgent.predict's input: the canonical observation (envs/ewn.py:289-296), its root moves, its playout stream
+                cst = canonicalize<1>(g, s);
+                pb0[tid] = pstate_from_gstate(g, cst);
+                pdice[tid] = (int8_t)dice;
+                pword[tid] = PlayoutRng::obs_word(r.seed_mix() * 0x9E3779B1u + r.draws(), 0x4D435453u, c.key);
+                n_root = for_each_legal<0, 1>(g, cst, dice, [](int, int, int) { return true; });
+            }
+        }
+        if (owner) {
+            #pragma unroll
+            for (int i = 0; i < 6; i++) wins[tid][i] = i < n_root ? 0 : -1;
+        }
+        if (tid == 0) { nlive_s = 0; next_slot = BS >> mr.gl; }
+        __syncthreads();
+        if (n_root > 0) { const int base = atomicAdd(&nlive_s, n_root); for (int i = 0; i < n_root; i++) livec[base + i] = (uint16_t)(tid * 8 + i); }
+        __syncthreads();
+        // ---- the playouts of the block's (game, root move) cells, mcts.py:47-69: a group of 2^gl lanes per cell; a group that has
+        // finished its cell takes the next unplayed one (results do not depend on who plays what)
+        const int nlive = nlive_s;
+        int slot = grp;
+        while (slot < nlive) {
+            const int cell = livec[slot], gi = cell >> 3, i = cell & 7;
+            if (glane == 0) nextc[grp] = tc;   // same wave as the lanes that read it: LDS operations of a wave execute in order
+            PState b0 = pb0[gi];
+            int w;
+            if (playout_root_move(&T, b0, g.S, pdice[gi], i)) w = glane < mr.total ? (mr.total - glane + tc - 1) >> mr.gl : 0;   // TOP_LEFT has won
+            else w = run_playouts<1>(&T, b0, g.S, pword[gi], (u32)(i * mr.total), glane, mr.total, &nextc[grp]);         // BOTTOM_RIGHT replies first
+            for (int off = tc >> 1; off > 0; off >>= 1) w += __shfl_down(w, off, tc);
+            if (glane == 0) { wins[gi][i] = w; myslot[grp] = atomicAdd(&next_slot, 1); }
+            __builtin_amdgcn_wave_barrier();
+            slot = myslot[grp];
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        if (reply) { // np.argmax over the root moves' wins (first maximum), that entry of the legal list (mcts.py:68), then envs/ewn.py:464-486
+            int best = 0, bw = -1;
+            #pragma unroll
+            for (int i = 0; i < 6; i++) { const int w = wins[tid][i]; if (w > bw) { bw = w; best = i; } }
+            int oflag = 0, odir = 0, j = 0;
+            for_each_legal<0, 1>(g, cst, dice, [&](int flag, int, int dir) { if (j == best) { oflag = flag; odir = dir; } j++; return j <= best; });
+            step_opponent<1>(g, c, s, dice, oflag, odir, r, nullptr, o);
+        }
+        if (active) {
+            ret_acc += o.reward; n_steps++; n_eps += o.term; n_wins += o.info == EWN_INFO_WON ? 1 : 0;
+            if (o.term) { if (c.autoreset) lane_auto_reset<1>(g, c, st.rng, lane, s, dice, r); else frozen = true; }
+        }
+        // ---- this step's trajectory row
+        if (live) {
+            const size_t oo = (size_t)kstep * c.N + lane;
+            if (B.t_action) ((uint16_t *)B.t_action)[oo] = (uint16_t)((uint8_t)aflag | ((uint16_t)(uint8_t)adir << 8));
+            if (B.t_dice) B.t_dice[oo] = (int8_t)dice;
+            if (B.t_reward) B.t_reward[oo] = o.reward;
+            if (B.t_term) B.t_term[oo] = (uint8_t)o.term;
+            if (B.t_trunc) B.t_trunc[oo] = (uint8_t)o.trunc;
+            if (B.t_info) B.t_info[oo] = (uint8_t)o.info;
+        }
+        if (B.t_board) {
+            if (live) encode_board<1>(g, s, lds + tid * g.cells);
+            __syncthreads();
+            block_copy_out(B.t_board + ((size_t)kstep * c.N + lane0) * g.cells, lds, nl * g.cells);
+            __syncthreads();
+        }
+        if (B.t_rec) { // one aligned record per lane-step: board | dice | action | flags | padding (ewn_rollout_out.record)
+            if (live) {
+                int8_t *rec = lds + tid * mr.strd;
+                for (int i = g.cells; i < mr.strd; i++) rec[i] = 0;
+                encode_board<1>(g, s, rec);
+                rec[g.cells] = (int8_t)dice; rec[g.cells + 1] = (int8_t)aflag; rec[g.cells + 2] = (int8_t)adir;
+                rec[g.cells + 3] = (int8_t)o.term; rec[g.cells + 4] = (int8_t)o.trunc; rec[g.cells + 5] = (int8_t)o.info;
+            }
+            __syncthreads();
+            block_copy_out((int8_t *)B.t_rec + ((size_t)kstep * c.N + lane0) * mr.strd, lds, nl * mr.strd);
+            __syncthreads();
+        }
+    }
+    if (live) encode_board<1>(g, s, lds + tid * g.cells);
+    if (live) {
+        if (!frozen0) { *rng_hdr_ptr(st.rng, lane) = r.header(); st.dice[lane] = (int8_t)dice; }
+        st.done[lane] = frozen ? 1 : 0;
+        if (B.ret_sum) B.ret_sum[lane] += ret_acc;
+        if (B.n_steps) B.n_steps[lane] += n_steps;
+        if (B.n_episodes) B.n_episodes[lane] += n_eps;
+        if (B.n_wins) B.n_wins[lane] += n_wins;
+    }
+    __syncthreads();
+    block_copy_out(st.board + (size_t)lane0 * g.cells, lds, nl * g.cells);
+}
+
 template <int NW>
 __global__ __launch_bounds__(BS) void k_mcts_pick(Geom g, int M, const int8_t *boards, const int8_t *dice, const int32_t *wins,
                                                   int8_t *actions)
@@ -963,6 +1131,16 @@ static int rollout_plan(const ewn_config *cfg, const Geom &g, const KCfg &k, int
     return EWN_OK;
 }
 
+// the flat Monte-Carlo opponent inside ewn_step_k (k_rollout_mcts): byte-per-cube playouts (cube_layer <= 3, boards <= 8x8), un-shaped,
+// RandomAgent / sample agents; MT19937-compat dice only without auto-reset (as every K-step kernel)
+static int mcts_rollout_plan(const ewn_config *cfg, const Geom &g, int agent_kind)
+{
+    if (cfg->opponent_kind != EWN_OPP_MCTS || cfg->shaped || g.CN > 6 || g.S > 8) return EWN_EUNSUPPORTED;
+    if (agent_kind != EWN_AGENT_RANDOM && agent_kind != EWN_AGENT_SAMPLE) return agent_kind == EWN_AGENT_MINIMAX ? EWN_EUNSUPPORTED : EWN_EINVAL;
+    if (cfg->rng_kind == EWN_RNG_MT19937 && cfg->autoreset) return EWN_EUNSUPPORTED;
+    return EWN_OK;
+}
+
 int ewn_lanes_per_game(const ewn_config *cfg, int entry)
 {
     Geom g; KCfg k;
@@ -989,6 +1167,7 @@ int ewn_step_k_supported(const ewn_config *cfg, int agent_kind, int agent_max_de
     int rc = check_cfg(cfg, g, k);
     if (rc) return rc;
     if (agent_kind == EWN_AGENT_MLP) { rc = ewn_policy_supported(cfg, g); return rc == EWN_OK ? 1 : (rc == EWN_EUNSUPPORTED ? 0 : rc); } // ewn_step_k_policy
+    if (cfg->opponent_kind == EWN_OPP_MCTS) { rc = mcts_rollout_plan(cfg, g, agent_kind); return rc == EWN_OK ? 1 : (rc == EWN_EUNSUPPORTED ? 0 : rc); }
     int T, opp, agent;
     rc = rollout_plan(cfg, g, k, agent_kind, agent_max_depth, T, opp, agent);
     return rc == EWN_OK ? 1 : (rc == EWN_EUNSUPPORTED ? 0 : rc);
@@ -1001,6 +1180,28 @@ int ewn_step_k(const ewn_config *cfg, const ewn_state *st, int K, int agent_kind
     int rc = check_cfg(cfg, g, k);
     if (rc) return rc;
     if (K < 1) return EWN_EINVAL;
+    if (cfg->opponent_kind == EWN_OPP_MCTS) {
+        if (!st || !st->board || !st->dice || !st->done || !st->rng) return EWN_ENULL;
+        rc = mcts_rollout_plan(cfg, g, agent_kind);
+        if (rc) return rc;
+        RollBuf rb;
+        memset(&rb, 0, sizeof(rb));
+        if (out) {
+            rb.t_board = out->board; rb.t_dice = out->dice; rb.t_action = out->action; rb.t_reward = out->reward;
+            rb.t_term = out->terminated; rb.t_trunc = out->truncated; rb.t_info = out->info; rb.t_rec = out->record;
+            rb.ret_sum = out->return_sum; rb.n_steps = out->n_steps; rb.n_episodes = out->n_episodes; rb.n_wins = out->n_wins;
+        }
+        // games per block: about 2 048 blocks (measured, us per step: 65 536 lanes MCTS(10 x 5) 473 / 426 / 449 / 485 at 16 / 32 / 64 / 128 games
+        // per block; 32 768 lanes 7x7 400 playouts 1 822 / 2 020 / 2 303 / 3 587) -- fewer, larger blocks starve the SIMDs of waves, smaller
+        // ones leave too few cells per barrier to balance.  EWN_MCTS_GPB overrides (tuning).
+        static const int gpb_env = [] { const char *e = getenv("EWN_MCTS_GPB"); const int v = e ? atoi(e) : 0; return v >= 8 && v <= MR_GPB ? v : 0; }();
+        int gpb = 8;
+        while (gpb < MR_GPB && (long long)k.N / (2 * gpb) >= 2048) gpb *= 2;
+        if (gpb_env) gpb = gpb_env;
+        MctsRoll mr = { K, k.nsim_total, playout_group_log2(k.nsim_total), agent_kind == EWN_AGENT_SAMPLE ? 1 : 0, (g.cells + 6 + 15) & ~15, gpb };
+        k_rollout_mcts<<<dim3((unsigned)((k.N + mr.gpb - 1) / mr.gpb)), BS, (size_t)mr.gpb * mr.strd, (hipStream_t)stream>>>(g, k, kstate(st), mr, rb);
+        return launch_status();
+    }
     if (!st || !st->board || !st->dice || !st->done || !st->rng || !st->tables) return EWN_ENULL;
     int T, opp, agent;
     rc = rollout_plan(cfg, g, k, agent_kind, agent_max_depth, T, opp, agent);

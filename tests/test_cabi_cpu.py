@@ -46,7 +46,11 @@ def test_step_k_availability_is_decided_on_the_host():
     assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=1, rng_kind=0, autoreset=1)), 0, 0) == 0
     assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=1, rng_kind=0, autoreset=0)), 1, 5) == 1
     assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=0, rng_kind=1)), 1, 3) == 1
-    assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=2, rng_kind=1)), 0, 0) == 0          # MCTS opponent: split-phase step only
+    assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=2, rng_kind=1)), 0, 0) == 1          # MCTS opponent: k_rollout_mcts (RandomAgent / sample agents)
+    assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=2, rng_kind=1)), 2, 0) == 1
+    assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=2, rng_kind=1)), 1, 3) == 0          # ... not with a minimax agent
+    assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=2, rng_kind=0, autoreset=1)), 0, 0) == 0
+    assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=2, rng_kind=1, shaped=1)), 0, 0) == 0
     assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=1, rng_kind=1, shaped=1)), 0, 0) in (0, 1)
     assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=1, rng_kind=1, board_size=7, cube_layer=4)), 0, 0) == 0
     assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=1, rng_kind=1)), 1, 7) == 0

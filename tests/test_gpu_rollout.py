@@ -113,6 +113,25 @@ def test_rollout_two_min_dist_opponent(ea, N, lo, kw):
                        philox_key=500 + kw["max_depth"], layout="record" if N == SLOT_N else "columns", **kw)
 
 
+@pytest.mark.parametrize("N,lo,n,K,kw", [
+    (600, 100, 300, 5, dict(num_simulations=10, num_env_copies=5)),                      # MCTS(10 x 5): the reference's default, eval_pairs.py:16
+    (300, 0, 200, 4, dict(num_simulations=3, num_env_copies=4, board_size=7)),
+    (700, 500, 200, 4, dict(num_simulations=2, num_env_copies=3, agent="sample")),
+    (260, 0, 260, 6, dict(num_simulations=4, num_env_copies=2, rng="mt19937", autoreset=False)),
+    (300, 40, 128, 3, dict(num_simulations=40, num_env_copies=10, layout="record")),     # 400 playouts per root move: groups of 64 lanes
+    (520, 256, 264, 4, dict(num_simulations=5, num_env_copies=5, board_size=6, layout="record")),
+], ids=lambda v: str(v) if not isinstance(v, dict) else "-".join("%s=%s" % kv for kv in sorted(v.items())))
+def test_rollout_mcts_opponent(ea, N, lo, n, K, kw):
+    """The flat Monte-Carlo opponent (classical_policies/mcts.py:21-106) inside ewn_step_k: agent half, playouts and opponent half as
+    the phases of one loop body (k_rollout_mcts), step for step against the oracle (which mirrors the playout generator)"""
+    kw = dict(kw)
+    agent = kw.pop("agent", "random")
+    rng = kw.pop("rng", "philox")
+    autoreset = kw.pop("autoreset", True)
+    layout = kw.pop("layout", "columns")
+    _rollout_vs_oracle(ea, N, lo, lo + n, K, 2, agent=agent, autoreset=autoreset, opponent_policy="mcts", rng=rng, philox_key=4242, layout=layout, **kw)
+
+
 def test_rollout_depth5_opponent(ea):
     _rollout_vs_oracle(ea, 200, 0, 96, 5, 2, opponent_policy="minimax", max_depth=5, rng="philox", philox_key=55)
 
