@@ -63,6 +63,58 @@ EWN_DEV float a2c_sum32(float x)
     return x;
 }
 
+// The loss of one sample at step t and its gradient d[] w.r.t. the head's outputs (SB3 A2C.train: policy_loss = -(adv * log_prob).mean(),
+// value_loss = mse(returns, values), entropy_loss = -entropy.mean(); loss = policy_loss + ent_coef * entropy_loss + vf_coef * value_loss).
+// NET 1 (value pass): the n-step return R_t = r_t + gamma (1 - done_t) R_{t+1} (GAE with lambda 1), the advantage R_t - V(s_t) left in
+// B.adv for the policy pass.  NET 0 (policy pass): two categoricals (flag: logits 0-1, direction: logits 2-4).  stat_lane: this lane
+// writes the advantage and counts the loss sums (one lane per sample).
+// what a step's loss needs besides the head outputs
+struct A2cStepIn { int a0, a1; bool term; float rew, adv; };
+template <int NET>
+EWN_DEV A2cStepIn a2c_step_in(const A2cCfg &c, const A2cBuf &B, const uint8_t *nrow, int cells, int t, int gc)
+{
+    A2cStepIn in;
+    in.a0 = nrow[cells + 1]; in.a1 = nrow[cells + 2]; in.term = nrow[cells + 3] != 0;
+    in.rew = NET == 1 ? (float)B.reward[(size_t)t * c.N + gc] : 0.0f;
+    in.adv = NET == 0 ? B.adv[(size_t)t * c.N + gc] : 0.0f;
+    return in;
+}
+
+template <int NET>
+EWN_DEV void a2c_loss_grad(const A2cCfg &c, const A2cBuf &B, const A2cStepIn &in, int t, int game, bool valid, bool stat_lane,
+                           const float *out, float &Rn, float (&d)[6], float &st_pl, float &st_vl, float &st_en)
+{
+    if constexpr (NET == 1) {
+        const float R = in.rew + (in.term ? 0.0f : c.gamma * Rn);
+        Rn = R;
+        const float V = out[0];
+        if (valid) {
+            if (stat_lane) { B.adv[(size_t)t * c.N + game] = R - V; st_vl += (R - V) * (R - V); }
+            d[0] = 2.0f * c.vf_coef * (V - R) * c.inv_batch;
+        }
+    } else {
+        const float *lg = out;
+        const int a0 = in.a0, a1 = in.a1;
+        const float adv = in.adv;
+        const float m0 = fmaxf(lg[0], lg[1]), m1 = fmaxf(lg[2], fmaxf(lg[3], lg[4]));
+        const float e0 = __expf(lg[0] - m0), e1 = __expf(lg[1] - m0), e2 = __expf(lg[2] - m1), e3 = __expf(lg[3] - m1), e4 = __expf(lg[4] - m1);
+        const float z0 = e0 + e1, z1 = e2 + e3 + e4, lz0 = __logf(z0), lz1 = __logf(z1);
+        const float pr[5] = { e0 / z0, e1 / z0, e2 / z1, e3 / z1, e4 / z1 };
+        const float lp[5] = { lg[0] - m0 - lz0, lg[1] - m0 - lz0, lg[2] - m1 - lz1, lg[3] - m1 - lz1, lg[4] - m1 - lz1 };
+        const float H0 = -(pr[0] * lp[0] + pr[1] * lp[1]), H1 = -(pr[2] * lp[2] + pr[3] * lp[3] + pr[4] * lp[4]);
+        const float logp = (a0 ? lp[1] : lp[0]) + (a1 == 0 ? lp[2] : (a1 == 1 ? lp[3] : lp[4]));
+        if (valid) {
+            if (stat_lane) { st_pl += -adv * logp; st_en += H0 + H1; }
+            #pragma unroll
+            for (int i = 0; i < 5; i++) {
+                const float oh = (i < 2 ? (a0 == i) : (a1 == i - 2)) ? 1.0f : 0.0f;
+                const float Hh = i < 2 ? H0 : H1;
+                d[i] = c.inv_batch * (-adv * (oh - pr[i]) + c.ent_coef * pr[i] * (lp[i] + Hh));   // d(-H)/dl_i = p_i (log p_i + H)
+            }
+        }
+    }
+}
+
 // NET 0: policy body + action head; NET 1: value body + value head.  NWV waves per block, one per SIMD.
 template <int S, int NET, int NWV>
 __global__ __launch_bounds__(NWV * 64, 1) void k_a2c_grad(A2cCfg c, A2cBuf B)
@@ -149,40 +201,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void k_a2c_grad(A2cCfg c, A2cBuf B)
             mlp_forward<S, NOUT>(L, lane, [&](int s) { return xrow[2 * s]; }, h1, h2, out);
             if (NET == 1 && t == c.K) { Rn = out[0]; continue; }   // V(s_K)
             // ---- the loss of step t and its gradient w.r.t. the head outputs (both lane halves hold the same numbers)
-            const uint8_t *nrow = B.rec + ((size_t)(t + 1) * c.N + gc) * STR;   // row t + 1: action a_t, flags of step t
+            const A2cStepIn sin = a2c_step_in<NET>(c, B, B.rec + ((size_t)(t + 1) * c.N + gc) * STR, CELLS, t, gc);   // row t + 1: action a_t, flags of step t
             float d[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
-            if constexpr (NET == 1) {
-                const float rew = (float)B.reward[(size_t)t * c.N + gc];
-                const bool term = nrow[CELLS + 3] != 0;
-                const float R = rew + (term ? 0.0f : c.gamma * Rn);
-                Rn = R;
-                const float V = out[0];
-                if (valid) {
-                    if (h == 0) { B.adv[(size_t)t * c.N + game] = R - V; st_vl += (R - V) * (R - V); }
-                    d[0] = 2.0f * c.vf_coef * (V - R) * c.inv_batch;
-                }
-            } else {
-                const float (&lg)[NOUT] = out;
-                const int a0 = nrow[CELLS + 1], a1 = nrow[CELLS + 2];
-                const float adv = B.adv[(size_t)t * c.N + gc];
-                // log-softmax of the two categoricals (flag: logits 0-1, direction: logits 2-4)
-                const float m0 = fmaxf(lg[0], lg[1]), m1 = fmaxf(lg[2], fmaxf(lg[3], lg[4]));
-                const float e0 = __expf(lg[0] - m0), e1 = __expf(lg[1] - m0), e2 = __expf(lg[2] - m1), e3 = __expf(lg[3] - m1), e4 = __expf(lg[4] - m1);
-                const float z0 = e0 + e1, z1 = e2 + e3 + e4, lz0 = __logf(z0), lz1 = __logf(z1);
-                const float pr[5] = { e0 / z0, e1 / z0, e2 / z1, e3 / z1, e4 / z1 };
-                const float lp[5] = { lg[0] - m0 - lz0, lg[1] - m0 - lz0, lg[2] - m1 - lz1, lg[3] - m1 - lz1, lg[4] - m1 - lz1 };
-                const float H0 = -(pr[0] * lp[0] + pr[1] * lp[1]), H1 = -(pr[2] * lp[2] + pr[3] * lp[3] + pr[4] * lp[4]);
-                const float logp = (a0 ? lp[1] : lp[0]) + (a1 == 0 ? lp[2] : (a1 == 1 ? lp[3] : lp[4]));
-                if (valid) {
-                    if (h == 0) { st_pl += -adv * logp; st_en += H0 + H1; }
-                    #pragma unroll
-                    for (int i = 0; i < 5; i++) {
-                        const float oh = (i < 2 ? (a0 == i) : (a1 == i - 2)) ? 1.0f : 0.0f;
-                        const float Hh = i < 2 ? H0 : H1;
-                        d[i] = c.inv_batch * (-adv * (oh - pr[i]) + c.ent_coef * pr[i] * (lp[i] + Hh));
-                    }
-                }
-            }
+            a2c_loss_grad<NET>(c, B, sin, t, game, valid, h == 0, out, Rn, d, st_pl, st_vl, st_en);
             // ---- head gradients
             if constexpr (NET == 1) {
                 #pragma unroll

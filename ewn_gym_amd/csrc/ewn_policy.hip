@@ -4,6 +4,7 @@
 #include "ewn_lds.hpp"
 #include "ewn_policy.hpp"
 #include "ewn_a2c.hpp"
+#include "ewn_a2c2.hpp"
 
 // which instantiation serves the configuration: opp 0 minimax (table image, max_depth 1-4), 1 RandomAgent
 static int policy_plan(const ewn_config *cfg, const Geom &g, int &opp)
@@ -118,9 +119,28 @@ int64_t ewn_a2c_scratch_bytes(const ewn_config *cfg, int K)
     return ((int64_t)K * k.N + (int64_t)A2C_MAX_BLOCKS * (P + 8) + 64) * 4;
 }
 
+// 5x5: two waves per tile (k_a2c_grad2); EWN_A2C_TEAM=0 selects the one-wave-per-tile kernel (A/B measurements)
+static int a2c_grad_launch_team(const A2cCfg &ac, A2cBuf ab, float *grad, hipStream_t s)
+{
+    constexpr size_t lds = A2c2Geo<5>::lds_bytes();
+    static_assert(lds <= 160 * 1024, "weight images + four teams' tiles must fit the CU's LDS");
+    auto kv = k_a2c_grad2<5, 1>;
+    auto kp = k_a2c_grad2<5, 0>;
+    if (hipFuncSetAttribute((const void *)kv, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return EWN_ELAUNCH;
+    if (hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return EWN_ELAUNCH;
+    const int blocks = a2c_blocks(ac.N, A2c2Geo<5>::TEAMS);
+    kv<<<blocks, 512, lds, s>>>(ac, ab);
+    kp<<<blocks, 512, lds, s>>>(ac, ab);
+    A2cRedBuf rb = { ab.partial, ab.stats, grad, blocks, MlpGeo<5>::P };
+    k_a2c_reduce<<<(MlpGeo<5>::P + 8 + A2C_RED_E - 1) / A2C_RED_E, 256, 0, s>>>(rb);
+    return launch_status();
+}
+
 template <int S>
 static int a2c_grad_launch(const A2cCfg &ac, A2cBuf ab, float *grad, hipStream_t s)
 {
+    static const bool team = [] { const char *e = getenv("EWN_A2C_TEAM"); return e ? atoi(e) != 0 : true; }();
+    if (S == 5 && team) return a2c_grad_launch_team(ac, ab, grad, s);
     constexpr int NWV = A2cWaves<S>::N;
     constexpr size_t lds = a2c_lds_bytes<S, NWV>();
     static_assert(lds <= 160 * 1024, "the gradient kernel's images and transpose tiles must fit the CU's LDS");
