@@ -12,7 +12,7 @@ import os
 import torch
 import torch.distributed as dist
 
-from .a2c import A2CTrainer
+from .a2c import A2CTrainer, FusedA2CTrainer
 from .sharding import all_reduce_counters, lane_range, lane_seeds
 from .tournament import evaluate
 from .vec_env import VecEWN
@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--batch_size", "-b", type=int, default=None,
                     help="PPO: minibatch size in samples of the n_steps x lanes rollout buffer (default: a quarter of it; train.py:178-183)")
     ap.add_argument("--n_epochs", type=int, default=10, help="PPO: passes over the rollout buffer per update (SB3 default)")
+    ap.add_argument("--trainer", default="auto", choices=["auto", "fused", "torch"],
+                    help="A2C only.  fused: the whole loop in the engine (ewn_step_k_policy + ewn_a2c_grad / ewn_a2c_apply, five kernel launches "
+                         "per update); torch: torch policy forward per step + ewn_step, autograd update; auto: fused where the engine has it")
     ap.add_argument("--checkpoint", default=None, help="path of a checkpoint written by this trainer to resume from (train.py:137-139, 248-251)")
     ap.add_argument("--model_seed", type=int, default=None, help="seed of the policy initialisation and sampling (default: --env_seed)")
     ap.add_argument("--num_envs", "-ne", type=int, default=4096, help="lanes per GPU")
@@ -63,12 +66,16 @@ def main():
     if a.algorithm == "PPO":   # train.py:39-49: SB3's PPO with batch_size and learning_rate given, the rest at its defaults (ewn_gym_amd/ppo.py)
         from .ppo import PPOTrainer
         trainer = PPOTrainer(env, n_steps=a.n_steps, batch_size=a.batch_size, n_epochs=a.n_epochs, learning_rate=a.learning_rate, seed=mseed)
+    elif a.trainer == "fused" or (a.trainer == "auto" and env.supports_policy_rollout()):
+        trainer = FusedA2CTrainer(env, n_steps=a.n_steps, learning_rate=a.learning_rate, seed=mseed)
     else:
         trainer = A2CTrainer(env, n_steps=a.n_steps, learning_rate=a.learning_rate, seed=mseed)
     if a.checkpoint is not None:      # train.py:137-139: resume the model (and here the optimiser and the step counter too)
         trainer.load(a.checkpoint)
         if rank == 0:
             print(json.dumps({"resumed_from": a.checkpoint, "timesteps": trainer.num_timesteps * world}), flush=True)
+    if rank == 0:
+        print(json.dumps({"trainer": type(trainer).__name__, "lanes_per_gpu": a.num_envs, "world": world}), flush=True)
     best = trainer.best_score   # -1 for a fresh run; a resumed one keeps its best model until it is beaten
     for epoch in range(a.epoch_num):
         stats = trainer.learn(a.timesteps_per_epoch // world)   # dict of the last update's statistics

@@ -122,3 +122,40 @@ def test_config4_a2c_on_shaped_env_with_minimax_opponent_65536_lanes(ea):
     assert illegal > 0                      # an untrained policy does play illegal moves: the tolerance path was exercised
     assert any(not torch.equal(a, b) for a, b in zip(p0, tr.model.parameters()))
     assert tr.num_timesteps == U * T * N
+
+
+def test_config4_fused_a2c_65536_lanes(ea):
+    """BASELINE config 4 per GPU on the fused path (FusedA2CTrainer: ewn_step_k_policy + ewn_a2c_grad + ewn_a2c_apply, what
+    train_a2c.py runs by default): 65 536 lanes, shaped env, depth-3 minimax opponent, n_steps 5.  Every transition of every
+    rollout of a 96-lane slice -- observation the policy saw, action, reward, flags -- is replayed on the oracle across eager,
+    captured and replayed updates; the parameters move, the loss statistics are finite."""
+    from ewn_gym_amd.a2c import FusedA2CTrainer
+    N, lo, hi, T, U = 65536, 40000, 40096, 5, 4
+    kw = dict(max_depth=3, rng="philox", shaped=True, reward=10.0, illegal_move_reward=-1.0, illegal_move_tolerance=10,
+              shaped_refresh_on_reset=True, philox_key=9487)
+    env = ea.VecEWN(N, opponent_policy="minimax", autoreset=True, seed_stride=N, **kw)
+    seeds = (np.arange(N, dtype=np.uint64) + 9487).astype(np.uint32)
+    env.reset(seeds=seeds)
+    orc = po.OracleVecEnv(hi - lo, opponent="minimax", autoreset=True, seed_stride=N, lane_offset=lo, **kw)
+    ob, od = orc.reset(seeds=seeds[lo:hi])
+    tr = FusedA2CTrainer(env, n_steps=T, learning_rate=7e-4, seed=1)
+    p0 = tr.params.clone()
+    illegal = 0
+    for u in range(U):                      # update 0 runs eagerly, 1 captures the five launches in a hipGraph, 2.. replay it
+        tr.collect_and_update()
+        stats = tr.stats_dict()
+        assert all(np.isfinite(v) for v in stats.values()), stats
+        tj = tr.traj
+        for t in range(T):
+            assert np.array_equal(cpu(tj["obs_board"][t, lo:hi]), ob) and np.array_equal(cpu(tj["obs_dice"][t, lo:hi]), od), (u, t)
+            ob, od, r, te, trn, info = orc.step(cpu(tj["action"][t, lo:hi]))
+            assert np.array_equal(bits(cpu(tj["reward"][t, lo:hi])), bits(r)), (u, t)
+            assert np.array_equal(cpu(tj["terminated"][t, lo:hi]), te) and np.array_equal(cpu(tj["info"][t, lo:hi]), info), (u, t)
+            illegal += int(((info == 1) | (info == 5)).sum())
+        assert np.array_equal(cpu(tj["obs_board"][T, lo:hi]), ob)            # s_K: the bootstrap observation
+    assert np.array_equal(cpu(env.board[lo:hi]), ob) and np.array_equal(cpu(env.dice[lo:hi]), od)
+    ps, tol, _ = orc.aux()
+    assert np.array_equal(bits(cpu(env.prev_score[lo:hi])), bits(ps)) and np.array_equal(cpu(env.tolerance[lo:hi]), tol)
+    assert illegal > 0
+    assert not torch.equal(p0, tr.params) and bool(torch.isfinite(tr.params).all())
+    assert tr.num_timesteps == U * T * N

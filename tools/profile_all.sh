@@ -15,9 +15,18 @@ timeout -k 10 200 $R/tools/profile_cfg.sh $O d5_k50 --max-depth 5 --steps 150 --
 cd $R
 timeout -k 10 300 tools/sweep_rollout.sh $O/sweep_rollout.txt > /dev/null 2>&1; tail -3 $O/sweep_rollout.txt
 timeout -k 10 100 python3 tools/eval_time.py > $O/eval_time.txt 2>&1
-for p in "" mcts predict r02 d5 long; do
+for p in "" r02 d5 r03; do
   timeout -k 10 600 python3 tools/soak_parity.py $p > $O/soak_${p:-step}.log 2>&1; echo rc=$? >> $O/soak_${p:-step}.log; tail -2 $O/soak_${p:-step}.log
 done
 timeout -k 10 200 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout -k 10 120 python3 bench.py --steps 20 --warmup 5 > $O/bench_driver_shape.json 2>/dev/null
+# round 3: the MT19937-compat one-step path, the MCTS opponent both ways, the A2C trainers (throughput un-profiled, then rocprofv3 kernel stats)
+for o in minimax random; do timeout -k 10 120 python3 bench.py --rng mt19937 --mode step --opponent $o --steps 1000 --warmup 100 --no-cpu-baseline --no-extras > $O/bench_mt19937_step_$o.json 2>/dev/null; done
+for m in rollout step; do
+  timeout -k 10 120 python3 bench.py --opponent mcts --num-simulations 10 --num-env-copies 5 --steps 100 --warmup 10 --steps-per-launch 20 --mode $m --no-cpu-baseline --no-extras > $O/bench_mcts5_$m.json 2>/dev/null
+  timeout -k 10 120 python3 bench.py --opponent mcts --board-size 7 --lanes 32768 --num-simulations 40 --num-env-copies 10 --steps 20 --warmup 4 --steps-per-launch 10 --mode $m --no-cpu-baseline --no-extras > $O/bench_mcts7_$m.json 2>/dev/null
+done
+timeout -k 10 400 tools/profile_a2c.sh $O/a2c > /dev/null 2>&1; cat $O/a2c/throughput.txt
+[ -x tools/bin/mfma_probe ] || { mkdir -p tools/bin; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -std=c++17 -o tools/bin/mfma_probe tools/mfma_probe.hip; }
+timeout -k 10 60 tools/bin/mfma_probe 2000 > $O/mfma_probe.txt 2>&1
 echo all done

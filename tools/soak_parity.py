@@ -178,3 +178,33 @@ if len(sys.argv) > 1 and sys.argv[1] == "r02":
     roll(1024, 10, 4, 0, 512, agent="minimax", agent_max_depth=5, autoreset=False, opponent_policy="random", rng="mt19937")
     roll(512, 10, 3, 0, 256, agent="minimax", agent_max_depth=3, autoreset=False, opponent_policy="minimax", max_depth=5, rng="philox", philox_key=36)
     print("r02 soak passed")
+
+if len(sys.argv) > 1 and sys.argv[1] == "r03":
+    # round-3 paths beyond the suite's sizes, through the suite's own lock-step helpers: record-layout rollouts at 262 144 / 1 M lanes,
+    # 'two_min_dist' and flat-Monte-Carlo opponents inside ewn_step_k, the policy-driven rollout (logits / values vs torch fp32, every
+    # transition vs the oracle, shaped env) over many launches, the MT19937-compat step at 65 536 lanes over many auto-resets (the
+    # refill requests now go straight to their global list), and the fused A2C gradient at 65 536 lanes vs torch autograd
+    from tests import test_gpu_rollout as tr, test_gpu_policy as tp, test_gpu_a2c_fused as tf
+    t0 = time.time()
+    for N, lo in ((262144, 200000), (1048576, 1040000)):
+        n = tr._rollout_vs_oracle(ea, N, lo, lo + 1024, 25, 4, layout="record", opponent_policy="minimax", max_depth=3, rng="philox", philox_key=31)
+        print("ok record rollouts N=%d: %d episodes in the slice (%.1f s)" % (N, n, time.time() - t0), flush=True)
+    n = tr._rollout_vs_oracle(ea, 140000, 70000, 71024, 30, 3, layout="record", opponent_policy="minimax", max_depth=3, heuristic="two_min_dist", rng="philox", philox_key=32)
+    print("ok two_min_dist rollouts: %d episodes (%.1f s)" % (n, time.time() - t0), flush=True)
+    n = tr._rollout_vs_oracle(ea, 66000, 1000, 1768, 12, 3, opponent_policy="minimax", max_depth=4, heuristic="two_min_dist", rng="philox", philox_key=33, board_size=7)
+    print("ok two_min_dist 7x7 depth 4: %d episodes (%.1f s)" % (n, time.time() - t0), flush=True)
+    n = tr._rollout_vs_oracle(ea, 20000, 9000, 9512, 10, 3, opponent_policy="mcts", num_simulations=10, num_env_copies=5, rng="philox", philox_key=34, layout="record")
+    print("ok MCTS(10 x 5) rollouts: %d episodes (%.1f s)" % (n, time.time() - t0), flush=True)
+    n = tr._rollout_vs_oracle(ea, 3000, 0, 256, 6, 2, opponent_policy="mcts", num_simulations=40, num_env_copies=10, rng="philox", philox_key=35, board_size=7)
+    print("ok MCTS 7x7 400 playouts rollouts: %d episodes (%.1f s)" % (n, time.time() - t0), flush=True)
+    kw = dict(opponent_policy="minimax", max_depth=3, shaped=True, reward=10.0, illegal_move_reward=-1.0, illegal_move_tolerance=10,
+              shaped_refresh_on_reset=True, philox_key=9487)
+    n = tp._policy_vs_torch_and_oracle(ea, 65536, 30000, 32000, 5, 24, **kw)
+    print("ok policy rollouts 65 536 lanes, 24 launches x 5 steps, 2 000-lane slice: %d episodes (%.1f s)" % (n, time.time() - t0), flush=True)
+    n = tp._policy_vs_torch_and_oracle(ea, 262144, 262144 - 1500, 262144, 8, 6, opponent_policy="random", philox_key=36)
+    print("ok policy rollouts 262 144 lanes, RandomAgent opponent: %d episodes (%.1f s)" % (n, time.time() - t0), flush=True)
+    run(65536, 150, 64000, 65536, opponent_policy="minimax", max_depth=3, rng="mt19937")
+    run(65536, 150, 0, 1536, opponent_policy="random", rng="mt19937")
+    tf.test_fused_gradient_matches_torch_autograd(ea, 65536, 5, 5, 0.0, "minimax")
+    tf.test_fused_gradient_matches_torch_autograd(ea, 131072, 5, 7, 0.01, "minimax")
+    print("ok fused A2C gradient vs torch autograd at 65 536 x 5 and 131 072 x 7 samples (%.1f s)" % (time.time() - t0), flush=True)
