@@ -70,8 +70,8 @@ def parse():
     ap.add_argument("--mt-window", type=int, default=0, help="MT19937-compat mode: precomputed outputs per episode window (0 = engine default)")
     ap.add_argument("--no-spin", action="store_true", help="skip the clock warm-up on a scratch env before the timed region")
     ap.add_argument("--spin-ms", type=float, default=6.0,
-                    help="approximate length of that clock warm-up (measured on the driver's 20-step shape, five runs each: 6 ms 6.06-6.18 G steps/s, "
-                         "30 ms 5.3-6.1, 100 ms 5.6-6.0, 250 ms 2.9-5.5 -- after a long eager queue the single graph launch starts late)")
+                    help="minimum length of that clock warm-up; it goes on, in ~1 ms chunks that are each waited for, until the scratch env's step "
+                         "time is stable (300 ms at most)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="run the N>1 code path (process group, barrier, MAX / ones / digest all-reduces) even at WORLD_SIZE=1: "
                          "exercises the RCCL branch on a one-GPU box")
@@ -362,7 +362,10 @@ def main():
     env = make_env()
     mode = args.mode
     if mode == "auto":
-        mode = "rollout" if (not args.separate_agent_kernel and env.supports_rollout("sample" if args.agent == "uniform6" else "random")) else "step"
+        # the flat Monte-Carlo opponent has a K-step kernel too (k_rollout_mcts), but its per-step block barriers cost more than the two
+        # launches they save (65 536 lanes MCTS(10 x 5): 426 us per step against 408): auto keeps the three-launch step for it
+        mode = "rollout" if (not args.separate_agent_kernel and args.opponent != "mcts"
+                             and env.supports_rollout("sample" if args.agent == "uniform6" else "random")) else "step"
     runner = Runner(torch, env, args, mode, trajectory=not args.no_trajectory, agent=args.agent)
     runner.launch(args.warmup)                                   # W untimed warm-up steps
     # Clock warm-up.  Between the warm-up steps and the timed region the host captures, instantiates and uploads the graph(s): the
@@ -379,8 +382,24 @@ def main():
         scratch.launch(k0)
         torch.cuda.synchronize()
         est = max(1e-7, (time.perf_counter() - t0) / k0)         # seconds per env step, roughly (this configuration, eager)
-        spin_steps = max(1, min(100000, int(args.spin_ms * 1e-3 / est)))
-        spin = lambda: scratch.launch(spin_steps)   # noqa: E731
+        chunk = max(k0, min(100000, int(1e-3 / est)))            # ~1 ms of scratch steps per chunk
+
+        def spin():
+            # chunks of scratch steps, each waited for (nothing stays queued in front of the timed launch), until the per-step time has
+            # stopped improving for three chunks in a row -- the clocks are up -- and at least --spin-ms have passed; 300 ms at most.  A fixed
+            # 6 ms was enough after a short idle phase, not after the 15 s of host-only work of the cpu_baseline leg (a default run then
+            # measured its first 2 000 steps at a fifth of the rate of the runs behind it).
+            t_begin, best, stable = time.perf_counter(), None, 0
+            while True:
+                t0 = time.perf_counter()
+                scratch.launch(chunk)
+                torch.cuda.synchronize()
+                now = time.perf_counter()
+                dt = (now - t0) / chunk
+                stable = stable + 1 if (best is not None and dt > 0.97 * best) else 0
+                best = dt if best is None else min(best, dt)
+                if (stable >= 3 and now - t_begin >= args.spin_ms * 1e-3) or now - t_begin >= 0.3:
+                    break
     dt, ev_ms = runner.run(args.steps, barrier, use_graph=not args.no_graph, spin=spin)   # exactly K timed steps
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if (dist_on and args.backend == "nccl") else "cpu")
     ranks_seen = None
@@ -483,7 +502,7 @@ def main():
                        "lanes_per_gpu": N, "board_size": args.board_size, "cube_layer": args.cube_layer,
                        "opponent": args.opponent, "max_depth": args.max_depth, "rng": args.rng, "mode": mode, "launch": launch,
                        "kernel_launches_in_timed_region": launches,
-                       "clock_warmup": None if args.no_spin else "a scratch env of the same configuration stepped ~%g ms right before the timed region (untimed, other state)" % args.spin_ms,
+                       "clock_warmup": None if args.no_spin else "a scratch env of the same configuration stepped in ~1 ms chunks until its step time is stable (>= %g ms, <= 300 ms) right before the timed region (untimed, other state)" % args.spin_ms,
                        "parallelism": "lanes sharded across %d GPU(s), no data-path collective" % world},
             "rccl_ranks": ranks_seen if args.backend == "nccl" else None,
             "collective": {"backend": args.backend if dist_on else None, "ranks": ranks_seen},

@@ -76,9 +76,10 @@ static void run(const char *name, int waves_per_simd, int reps, float *out, u64 
     hipMemcpy(h.data(), cyc, h.size() * sizeof(u64), hipMemcpyDeviceToHost);
     std::sort(h.begin(), h.end());
     const double med = (double)h[h.size() / 2];
-    // s_memtime ticks at 100 MHz on gfx9 (constant clock): report ticks per 8-MFMA group and ns
-    printf("%-34s waves/SIMD %d  NF %2d : %.3f ticks per group of 8 (median wave), = %.1f ns per MFMA slot\n", name, waves_per_simd, NF,
-           med / reps, med / reps / 8.0 * 10.0);
+    // s_memtime ticks at the shader clock (MI355X_MICROARCH.md constants table): cycles per slot = one MFMA (if any) + its NF fillers,
+    // as seen by one wave; with two waves per SIMD both waves' slots share the SIMD, so the SIMD spends half of that per slot
+    printf("%-34s waves/SIMD %d  NF %2d : %7.1f cycles per slot and wave  (%6.1f per slot and SIMD)\n", name, waves_per_simd, NF,
+           med / reps / 8.0, med / reps / 8.0 / waves_per_simd);
 }
 
 int main(int argc, char **argv)
