@@ -461,7 +461,7 @@ def main():
                 if ent and pmc.get("source_hash") == source_hash():
                     traffic = ent["hbm_bytes_per_launch"]
                     rocprof_ms = ent.get("rocprof_avg_us", 0.0) / 1e3 or None
-                    vi, peak = ent.get("valu_wave_insts_per_launch"), pmc.get("valu_issue_peak_per_s")
+                    vi, peak = ent.get("valu_wave_insts_per_launch"), ent.get("valu_issue_peak_per_s") or pmc.get("valu_issue_peak_per_s")   # the entry's own mix, if priced
                     if vi and peak:
                         valu = {"wave_insts_per_launch": vi, "achieved_per_s": vi / (kms * 1e-3), "peak_per_s": peak,
                                 "frac": vi / (kms * 1e-3) / peak,
@@ -473,7 +473,9 @@ def main():
                 traffic = valu = None
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "valu_issue": valu,
-                "kernel": "k_rollout_slots / k_rollout_d3 (K fused env steps per launch; the slot-task kernel from 131 072 lanes x lanes-per-game)" if mode == "rollout" else "k_step (fused agent move + opponent search + reply + auto-reset)",
+                "kernel": ("k_rollout_slots / k_rollout_d3 (K fused env steps per launch; the slot-task kernel from 131 072 lanes x lanes-per-game)" if mode == "rollout"
+                           else ("k_mcts_rollout_lean (the playouts: ~97 % of the step; traffic / valu_issue are this kernel's) between the two half-step kernels" if args.opponent == "mcts"
+                                 else "k_step (fused agent move + opponent search + reply + auto-reset)")),
                 "kernel_ms": kms, "kernel_ms_rocprof": rocprof_ms, "env_steps_per_launch": steps_per_launch, "algorithmic_bytes_per_launch": algo,
                 "note": "integer/fp64-compare search work: VALU-bound, far from the HBM roof by construction (SURVEY 8d); kernel_ms = one HIP "
                         "event pair on the launch stream around the timed region / launches; kernel_ms_rocprof = rocprofv3 --kernel-trace --stats average of the same "

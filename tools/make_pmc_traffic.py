@@ -55,15 +55,25 @@ def main():
     out = {"source_hash": source_hash(), "git_head_when_summarised": head}
     mixp = os.path.join(dst, "isa_mix.json")
     probe = os.path.join(dst, "valu_probe.json")
-    cfgs = (("rollout_k50", "k_rollout", pmc_key("rollout", "minimax", 3, "philox", 5, 65536, 50, True), 50),
-            ("rollout_k20", "k_rollout", pmc_key("rollout", "minimax", 3, "philox", 5, 65536, 20, True), 20),
-            ("rollout_k50_notraj", "k_rollout", pmc_key("rollout", "minimax", 3, "philox", 5, 65536, 50, False), 50),
-            ("step", "k_step_d3", pmc_key("step", "minimax", 3, "philox", 5, 65536, 1, True), 1))
-    for name, kern, key, K in cfgs:
+    # (directory, dominant kernel, bench.py's key, env steps per launch of that kernel, lanes, isa_mix kernel substring for its own issue peak)
+    cfgs = (("rollout_k50", "k_rollout", pmc_key("rollout", "minimax", 3, "philox", 5, 65536, 50, True), 50, 65536, None),
+            ("rollout_k20", "k_rollout", pmc_key("rollout", "minimax", 3, "philox", 5, 65536, 20, True), 20, 65536, None),
+            ("rollout_k50_notraj", "k_rollout", pmc_key("rollout", "minimax", 3, "philox", 5, 65536, 50, False), 50, 65536, None),
+            ("step", "k_step_d3", pmc_key("step", "minimax", 3, "philox", 5, 65536, 1, True), 1, 65536, None),
+            # round 3: the max_depth 5 rollout and the flat Monte-Carlo step (config 5's per-GPU shape) carry their own counters and issue peak
+            ("d5_k50", "k_rollout", pmc_key("rollout", "minimax", 5, "philox", 5, 65536, 50, True), 50, 65536, "k_rollout_slotsILi5ELi2ELi2ELi1ELb0E"),
+            ("mcts7", "k_mcts_rollout_lean", pmc_key("step", "mcts", 3, "philox", 7, 32768, 1, True), 1, 32768, "k_mcts_rollout_lean"))
+    mix_all = json.load(open(mixp)) if os.path.exists(mixp) else {"kernels": {}}
+    for name, kern, key, K, lanes, mixsub in cfgs:
         d = os.path.join(src, name)
         if not os.path.isdir(d):
             continue
-        ent = {"lanes": 65536, "env_steps_per_launch": K}
+        ent = {"lanes": lanes, "env_steps_per_launch": K}
+        if mixsub:
+            for kname, kv in mix_all["kernels"].items():
+                if mixsub in kname and "peak_wave_insts_per_s" in kv:
+                    ent["valu_issue_peak_per_s"] = kv["peak_wave_insts_per_s"]["hot_loop"]
+                    ent["valu_issue_peak_source"] = "tools/isa_mix.py hot loop of %s" % kname
         st = os.path.join(d, "stats_kernel_stats.csv")
         if os.path.exists(st):
             for r in csv.DictReader(open(st)):
@@ -93,11 +103,11 @@ def main():
         if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
             ent["FETCH_SIZE_KB_raw"], ent["WRITE_SIZE_KB_raw"] = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
             ent["hbm_bytes_per_launch"] = (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024
-            ent["per_lane_step_fetch_raw_B"] = vals["FETCH_SIZE"] * 1024 / 65536 / K
-            ent["per_lane_step_write_raw_B"] = vals["WRITE_SIZE"] * 1024 / 65536 / K
+            ent["per_lane_step_fetch_raw_B"] = vals["FETCH_SIZE"] * 1024 / lanes / K
+            ent["per_lane_step_write_raw_B"] = vals["WRITE_SIZE"] * 1024 / lanes / K
         if "SQ_INSTS_VALU" in vals:
             ent["valu_wave_insts_per_launch"] = vals["SQ_INSTS_VALU"]
-            ent["valu_wave_insts_per_lane_step"] = vals["SQ_INSTS_VALU"] / 65536 / K
+            ent["valu_wave_insts_per_lane_step"] = vals["SQ_INSTS_VALU"] / lanes / K
         for c in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_LDS", "SQ_WAVES"):
             if c in vals:
                 ent[c] = vals[c]
