@@ -9,9 +9,23 @@
 // what one wave waits for the other issues under.  What crosses between the two waves goes through the LDS transposes that the
 // sample-contracting products need anyway: T(h1) and T(g2) ([sample][unit], both halves) double as the other half's B operands of
 // layer 2 and of dh1 = W2^T g2 (lane (j, h) reads unit kcol(ks, h) of its own sample j: one conflict-free ds_read per k-step).
-// Four block barriers per step order the phases (the games of a block are in lock step; teams are independent otherwise).
+// Four meetings of the team's two waves per step order the phases (a2c_team_sync: per-team LDS flags, not block barriers).
 #pragma once
 #include "ewn_a2c.hpp"
+
+// The two waves of a team meet; nobody else is involved.  A block barrier would do (all teams run the same sequence), but it ties the
+// four teams of a block -- and with them the two waves that share a SIMD, which belong to different teams -- into one phase: measured
+// (PMC) the SIMDs then sat idle 27 % of the kernel, both of their waves waiting.  Per-team flags let the teams drift apart, so that one
+// wave's MFMA chain runs while its SIMD neighbour waits for its own partner.  flag[m] = how many meetings wave m has reached; LDS
+// operations of a wave complete in order, so the partner that sees my count also sees everything I stored before it.
+EWN_DEV void a2c_team_sync(volatile int *flag, int m, int lane, int &epoch)
+{
+    epoch++;
+    asm volatile("" ::: "memory");
+    if (lane == 0) flag[m] = epoch;
+    while (flag[1 - m] < epoch) __builtin_amdgcn_s_sleep(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
 
 template <int S> struct A2c2Geo {
     using G = MlpGeo<S>;
@@ -20,7 +34,8 @@ template <int S> struct A2c2Geo {
     static constexpr int XS = 33;                                   // [sample][feature] row stride
     // per team: XT x 2 (double-buffered: features of step t are written while the other wave may still read step t + 1's) | TA | TB | Dt | PX
     static constexpr int O_XT = 0, O_TA = O_XT + 2 * 32 * XS, O_TB = O_TA + 32 * A2C_TS, O_DT = O_TB + 32 * A2C_TS, O_PX = O_DT + 32 * 8;
-    static constexpr int TEAM_FLOATS = O_PX + 2 * 8 * 32;
+    static constexpr int O_FLAG = O_PX + 2 * 8 * 32;                // two meeting counters (a2c_team_sync)
+    static constexpr int TEAM_FLOATS = O_FLAG + 4;
     static constexpr int TEAMS = 4;
     static constexpr size_t lds_bytes() { return ((size_t)A::L_NET_END + (size_t)TEAMS * TEAM_FLOATS) * 4; }
 };
@@ -40,6 +55,8 @@ __global__ __launch_bounds__(512, 2) void k_a2c_grad2(A2cCfg c, A2cBuf B)
     const int team = wave >> 1, m = wave & 1;        // my tile of hidden units: 32 m .. 32 m + 31
     float *TM = L + A::L_NET_END + team * Q::TEAM_FLOATS;
     float *TA = TM + Q::O_TA, *TB = TM + Q::O_TB, *Dt = TM + Q::O_DT, *PX = TM + Q::O_PX;
+    volatile int *flag = (volatile int *)(TM + Q::O_FLAG);
+    int epoch = 0;
     float *GI = L + A::L_NET_END;                    // at the end: the block's gradient image (over the team areas)
 
     mlp_pack_net<S>(L, B.params, NET, threadIdx.x, NT);
@@ -56,6 +73,7 @@ __global__ __launch_bounds__(512, 2) void k_a2c_grad2(A2cCfg c, A2cBuf B)
         }
     }
     for (int e = m * 64 + lane; e < 32 * 8; e += 128) Dt[e] = 0.0f;
+    if (lane < 2 && m == 0) flag[lane] = 0;
     __syncthreads();
 
     // my rows of the gradient: dW2 [32 m + row][64], dW1 [32 m + row][32 features], the head's columns 32 m .. (pi: a 32 x 32 MFMA tile
@@ -67,7 +85,7 @@ __global__ __launch_bounds__(512, 2) void k_a2c_grad2(A2cCfg c, A2cBuf B)
     const int tiles = (c.N + 31) / 32, stride = (int)gridDim.x * Q::TEAMS, iters = (tiles + stride - 1) / stride;
     int parity = 0;
     #pragma unroll 1
-    for (int it = 0; it < iters; it++) {            // the same trip count for every wave of the block: the barriers below are block-wide
+    for (int it = 0; it < iters; it++) {            // the same trip count for both waves of a team (their meetings must pair up)
         const int tile = it * stride + (int)blockIdx.x * Q::TEAMS + team;
         const int game = tile * 32 + j;
         const bool valid = tile < tiles && game < c.N;
@@ -80,21 +98,21 @@ __global__ __launch_bounds__(512, 2) void k_a2c_grad2(A2cCfg c, A2cBuf B)
             parity ^= 1;
             const uint8_t *rrow = B.rec + ((size_t)t * c.N + gc) * STR;
             {
+                // all eight bytes unconditionally (a per-byte `if (k < CELLS)` on a lane-dependent k cost an exec-mask dance per store: a
+                // fifth of the loop's instructions): the lane with bytes 24 .. 31 stores the meta bytes as "features" 25 .. 31 too and
+                // then overwrites them with the dice one-hot itself (same lane, program order)
                 const uint2 v = *(const uint2 *)(rrow + 16 * m + 8 * h);
                 const u32 w[2] = { v.x, v.y };
+                float *xk = XT + j * Q::XS + 16 * m + 8 * h;
                 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const int k = 16 * m + 8 * h + i;
-                    const float f = (float)(int)(int8_t)((w[i >> 2] >> (8 * (i & 3))) & 0xFFu);
-                    if (k < CELLS) XT[j * Q::XS + k] = f;
-                }
-                if (m == 1 && h == 1) {             // this lane holds bytes 24 .. 31: cell 24, then the dice: the one-hot features 25 .. 31
+                for (int i = 0; i < 8; i++) xk[i] = (float)(int)(int8_t)((w[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+                if (m == 1 && h == 1) {             // bytes 24 .. 31: cell 24, then the dice at byte 25
                     const int dice = (int)(int8_t)((w[0] >> 8) & 0xFFu);
                     #pragma unroll
-                    for (int dd = 0; dd < 7; dd++) XT[j * Q::XS + CELLS + dd] = (dd == dice - 1) ? 1.0f : 0.0f;
+                    for (int dd = 0; dd < 7; dd++) xk[1 + dd] = (dd == dice - 1) ? 1.0f : 0.0f;
                 }
             }
-            __syncthreads();                        // (1) the tile's features are complete
+            a2c_team_sync(flag, m, lane, epoch);                        // (1) the tile's features are complete
             // ---- layer 1, my 32 units
             const int hh = h;
             f32x16 a = mlp_bias_acc(L + G::L_B1 + 32 * m, hh);
@@ -106,7 +124,7 @@ __global__ __launch_bounds__(512, 2) void k_a2c_grad2(A2cCfg c, A2cBuf B)
             const f32x16 h1 = mlp_tanh16(a);
             #pragma unroll
             for (int r = 0; r < 16; r++) TB[j * A2C_TS + 32 * m + mlp_row(r, h)] = h1[r];   // T(h1), my columns
-            __syncthreads();                        // (2) T(h1) complete: the other half's units are layer 2's remaining B operands
+            a2c_team_sync(flag, m, lane, epoch);                        // (2) T(h1) complete: the other half's units are layer 2's remaining B operands
             // ---- layer 2, my 32 units: k-steps of my own tile from registers, the other tile's from T(h1)
             f32x16 cacc = mlp_bias_acc(L + G::L_B2 + 32 * m, hh);
             #pragma unroll
@@ -137,7 +155,7 @@ __global__ __launch_bounds__(512, 2) void k_a2c_grad2(A2cCfg c, A2cBuf B)
                 }
                 if (h == 0) { for (int q = 0; q < NOUT; q++) PX[(m * 8 + q) * 32 + j] = out[q]; }
             }
-            __syncthreads();                        // (3) both waves' partial head outputs are in PX
+            a2c_team_sync(flag, m, lane, epoch);                        // (3) both waves' partial head outputs are in PX
             #pragma unroll
             for (int q = 0; q < NOUT; q++) {
                 const float p0 = PX[q * 32 + j], p1 = PX[(8 + q) * 32 + j];
@@ -186,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void k_a2c_grad2(A2cCfg c, A2cBuf B)
                 dW2[1] = MLP_MFMA(av, TB[(2 * s + h) * A2C_TS + 32 + j], dW2[1]);
                 if ((s & 3) == 3) MLP_SCHED_FENCE();
             }
-            __syncthreads();                        // (4) T(g2) complete, and nobody reads T(h1) any more
+            a2c_team_sync(flag, m, lane, epoch);                        // (4) T(g2) complete, and nobody reads T(h1) any more
             // ---- dh1 = W2^T g2 (my units): my own g2 from registers, the other half's from T(g2); g1 = dh1 (1 - h1^2)
             f32x16 g1 = (f32x16)(0.0f);
             #pragma unroll

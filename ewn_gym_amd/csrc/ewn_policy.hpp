@@ -11,7 +11,7 @@
 // SIMD -- while one wave's MFMAs run, the other's search has the VALU.
 #pragma once
 #include "ewn_rollout.hpp"
-#include "ewn_mlp.hpp"
+#include "ewn_mlp3.hpp"
 
 struct PolCfg {
     int N, autoreset, lane_offset, depth, K;
@@ -43,13 +43,12 @@ EWN_DEV void tables_to_lds_nt(int8_t *lds, const int8_t *g)
                                          (__attribute__((address_space(3))) void *)(lds + off), 16, 0, 0);
 }
 
-// LDS bytes of k_rollout_mlp<S, ., NT>
+// LDS bytes of k_rollout_mlp<S, ., NT>: table image | weight image(s) | 8 floats of head outputs per game | game slots | decode scratch
 template <int S, int NT>
 constexpr size_t pol_lds_bytes(bool want_value)
 {
-    using G = MlpGeo<S>;
-    constexpr int GPB = NT / 2, NW = NT / 64;
-    return (size_t)FAST_TAB_BYTES(S) + (size_t)(want_value ? 2 : 1) * G::L_END * 4 + (size_t)NW * (G::FP * 32 + 32 * 8) * 4
+    constexpr int GPB = NT / 2;
+    return (size_t)FAST_TAB_BYTES(S) + (size_t)(want_value ? 2 : 1) * Mlp3Geo<S>::FWD_BYTES + (size_t)GPB * 8 * 4
            + (size_t)GPB * RecGeo<S>::STR + (size_t)GPB * 16;
 }
 
@@ -61,6 +60,9 @@ EWN_DEV float pol_uniform(u32 w0, int i)
     return ((float)(w >> 9) + 0.5f) * (1.0f / 8388608.0f);
 }
 
+// ln x on v_log_f32 (log2, ~1 ulp) -- the Gumbel noise -ln(-ln u) ten times per game and step; the library logf is ~20 instructions each
+EWN_DEV float pol_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+
 // OPP 0: minimax max_depth 1-4 on a (level, count) table image; 1: RandomAgent.  Philox dice.
 template <int S, int OPP, int NT>
 __global__ __launch_bounds__(NT, NT / 256) void k_rollout_mlp(PolCfg c, PolBuf B)
@@ -68,19 +70,20 @@ __global__ __launch_bounds__(NT, NT / 256) void k_rollout_mlp(PolCfg c, PolBuf B
     constexpr int T = 2, GPB = NT / T, NW = NT / 64, CELLS = S * S, STR = RecGeo<S>::STR, NCH = RecGeo<S>::NCH;
     using G = MlpGeo<S>;
     extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+    using Q3 = Mlp3Geo<S>;
+    static_assert(Q3::FWD_BYTES % 16 == 0, "image alignment");
     int8_t *tb = lds;
-    float *Wpi = (float *)(lds + FAST_TAB_BYTES(S));
-    float *Wvf = Wpi + G::L_END;
-    float *xs_all = Wpi + (c.want_value ? 2 : 1) * G::L_END;
+    int8_t *Wpi = lds + FAST_TAB_BYTES(S);
+    int8_t *Wvf = Wpi + Q3::FWD_BYTES;
+    float *lx_all = (float *)(Wpi + (c.want_value ? 2 : 1) * Q3::FWD_BYTES);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float *Xs = xs_all + wave * (G::FP * 32 + 32 * 8);    // this wave's feature tile [feature][32 samples] ...
-    float *LX = Xs + G::FP * 32;                          // ... and its 8 floats per sample of head outputs
-    int8_t *slots = (int8_t *)(xs_all + NW * (G::FP * 32 + 32 * 8));
+    float *LX = lx_all + wave * 32 * 8;                    // this wave's 8 floats per game of head outputs
+    int8_t *slots = (int8_t *)(lx_all + GPB * 8);
     uint8_t *garr = (uint8_t *)(slots + GPB * STR);
     tables_to_lds_nt<FAST_TAB_BYTES(S), NT>(tb, (const int8_t *)B.tables);
     const FastTab<S> *Tb = (const FastTab<S> *)tb;
-    mlp_pack_net<S>(Wpi, B.params, 0, threadIdx.x, NT);
-    if (c.want_value) mlp_pack_net<S>(Wvf, B.params, 1, threadIdx.x, NT);
+    mlp3_pack_fwd<S>(Wpi, B.params, 0, threadIdx.x, NT);
+    if (c.want_value) mlp3_pack_fwd<S>(Wvf, B.params, 1, threadIdx.x, NT);
 
     const int g0 = (int)blockIdx.x * GPB, ng = min(GPB, c.N - g0);
     const int gl = threadIdx.x / T, sub = threadIdx.x % T, game = g0 + gl;
@@ -108,7 +111,6 @@ __global__ __launch_bounds__(NT, NT / 256) void k_rollout_mlp(PolCfg c, PolBuf B
     __syncthreads();                                       // every game is in registers: the board area becomes the per-game slots
     int8_t *slot = slots + gl * STR;
     rec_slot_build<S, T>(Tb, s, sub, slot);
-    if (G::FP > G::F) { for (int i = lane; i < (G::FP - G::F) * 32; i += 64) Xs[G::F * 32 + i] = 0.0f; }   // padding feature rows
     if (B.t_rec && c.rec0 && live) rec_store<S, T>(slot, sub, dice, 0, 0, 0, 0, 0, B.t_rec + (size_t)game * STR);
     double ret_acc = 0.0;
     int n_steps = 0, n_eps = 0, n_wins = 0;
@@ -123,39 +125,27 @@ __global__ __launch_bounds__(NT, NT / 256) void k_rollout_mlp(PolCfg c, PolBuf B
         double reward = 0.0;
         int term = 0, trunc = 0, info = EWN_INFO_NONE;
         if (live && frozen) term = 1;
-        // ---- features of the current observation: the board bytes of my game's slot (16 per lane and piece) as floats, the dice one-hot
+        // ---- the network(s): this wave's 32 games are the 32 columns of the MFMA tiles (game j of the wave = column j, both lane halves);
+        // the features come straight out of the games' slots: lane (j, h) turns bytes 16 kb + 8 h .. + 7 of game j's board into the eight
+        // bf16 of its k-block operand (the slot's bytes past the board are zero) and sets the dice one-hot (features CELLS .. CELLS + 6)
         __builtin_amdgcn_wave_barrier();
-        #pragma unroll
-        for (int c0 = 0; c0 < NCH; c0 += T) {
-            const int ch = c0 + sub;
-            if (ch < NCH) {
-                const uint4 v = ((const uint4 *)slot)[ch];
-                const u32 w[4] = { v.x, v.y, v.z, v.w };
-                #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    if (16 * c0 + i < CELLS) {             // some lane of the group may have a cell here ...
-                        const int k = 16 * ch + i;
-                        const float f = (float)(int)(int8_t)((w[i >> 2] >> (8 * (i & 3))) & 0xFFu);
-                        if (k < CELLS) Xs[k * 32 + jw] = f; // ... this one does
-                    }
-                }
-            }
-        }
-        if (sub == 0) {
-            #pragma unroll
-            for (int d = 0; d < 7; d++) Xs[(CELLS + d) * 32 + jw] = (d == dice - 1) ? 1.0f : 0.0f;
-        }
-        __builtin_amdgcn_wave_barrier();
-        // ---- the network(s): this wave's 32 games are the 32 columns of the MFMA tiles; every lane ends up with its column's outputs
         {
+            const int j = lane & 31, h = lane >> 5;
+            const int dj = __builtin_amdgcn_ds_bpermute((2 * j) << 2, dice);          // game j's dice (its lanes are 2 j, 2 j + 1)
+            const int8_t *sj = slots + (wave * 32 + j) * STR + 8 * h;
+            auto xb = [&](int kb) {
+                const uint2 v = *(const uint2 *)(sj + 16 * kb);
+                u32x4 o = mlp3_bytes_operand(v.x, v.y);
+                if (16 * kb + 15 >= CELLS && 16 * kb < CELLS + 7) o = mlp3_onehot(o, CELLS + dj - 1 - (16 * kb + 8 * h));
+                return o;
+            };
             f32x16 h1[2], h2[2];
             float lo[MLP_NA];
-            const float *xcol = Xs + (lane >> 5) * 32 + (lane & 31);
-            mlp_forward<S, MLP_NA>(Wpi, lane, [&](int st) { return xcol[st * 64]; }, h1, h2, lo);
+            mlp3_forward<S, MLP_NA>(Wpi, lane, xb, h1, h2, lo);
             if (lane < 32) { *(float4 *)(LX + lane * 8) = make_float4(lo[0], lo[1], lo[2], lo[3]); LX[lane * 8 + 4] = lo[4]; }
             if (c.want_value) {
                 float vo[1];
-                mlp_forward<S, 1>(Wvf, lane, [&](int st) { return xcol[st * 64]; }, h1, h2, vo);
+                mlp3_forward<S, 1>(Wvf, lane, xb, h1, h2, vo);
                 if (lane < 32) LX[lane * 8 + 5] = vo[0];
             }
         }
@@ -169,7 +159,7 @@ __global__ __launch_bounds__(NT, NT / 256) void k_rollout_mlp(PolCfg c, PolBuf B
         const u32 w0 = agent_hash(r.seed_mix() ^ ((u32)tol * 0x632BE5ABu), r.draws(), (u32)(c.lane_offset + game), c.key ^ c.noise_key);
         float u[5], gn[5];
         #pragma unroll
-        for (int i = 0; i < 5; i++) { u[i] = pol_uniform(w0, i); gn[i] = c.deterministic ? 0.0f : -__logf(-__logf(u[i])); }
+        for (int i = 0; i < 5; i++) { u[i] = pol_uniform(w0, i); gn[i] = c.deterministic ? 0.0f : -pol_log(-pol_log(u[i])); }
         const float z0 = lg.x + gn[0], z1 = lg.y + gn[1], z2 = lg.z + gn[2], z3 = lg.w + gn[3], z4 = lg4 + gn[4];
         const int aflag = z1 > z0 ? 1 : 0;
         const int adir = z3 > z2 ? (z4 > z3 ? 2 : 1) : (z4 > z2 ? 2 : 0);

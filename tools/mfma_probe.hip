@@ -13,6 +13,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned long long u64;
 
 #define MF(acc) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#define MB(acc) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a8), "v"(b8))
 #define VF(x) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x) : "v"(a))
 #define LR(x) asm volatile("ds_read_b32 %0, %1" : "=v"(x) : "v"(ldsaddr))
 #define VI(x) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x) : "v"(a))
@@ -26,6 +27,9 @@ __global__ void probe(float *out, u64 *cyc, int reps)
     f32x16 c0, c1;
     for (int i = 0; i < 16; i++) { c0[i] = 0.0f; c1[i] = 1.0f; }
     float a = 1.0f + threadIdx.x * 1e-9f, b = 0.5f;
+    typedef short bf16x8 __attribute__((ext_vector_type(8)));
+    bf16x8 a8, b8;
+    for (int i = 0; i < 8; i++) { a8[i] = (short)(0x3f80 + threadIdx.x % 3); b8[i] = (short)0x3f00; }
     float f[16];
     for (int i = 0; i < 16; i++) f[i] = (float)i;
     sm[threadIdx.x] = 1.0f;
@@ -53,6 +57,11 @@ __global__ void probe(float *out, u64 *cyc, int reps)
             }
             if (MODE == 6 || MODE == 7) { if (MODE == 6) MF(c0); _Pragma("unroll") for (int i = 0; i < NF; i++) VI(f[i & 15]); }   // integer VALU fillers
             if (MODE == 8 || MODE == 9) { if (MODE == 8) MF(c0); _Pragma("unroll") for (int i = 0; i < NF; i++) VE(f[i & 15]); }   // transcendental fillers
+            if (MODE == 11) MB(c0);                                                      // bf16 32x32x16: dependent chain
+            if (MODE == 12) { if (k & 1) MB(c1); else MB(c0); }                          // ... two chains
+            if (MODE == 13) { MB(c0); _Pragma("unroll") for (int i = 0; i < NF; i++) VF(f[i & 15]); }   // ... chain + fp32 VALU fillers
+            if (MODE == 14) { MB(c0); _Pragma("unroll") for (int i = 0; i < NF; i++) VI(f[i & 15]); }   // ... chain + integer VALU fillers
+            if (MODE == 15) { if (k & 1) MB(c1); else MB(c0); _Pragma("unroll") for (int i = 0; i < NF; i++) VI(f[i & 15]); }
             if (MODE == 10) { MF(c0); _Pragma("unroll") for (int i = 0; i < NF; i++) VC(f[i & 15]); }
         }
     }
@@ -105,6 +114,14 @@ int main(int argc, char **argv)
         run<8, 4>("chain + 4 v_exp_f32", w, reps, out, cyc);
         run<9, 4>("4 v_exp_f32 only", w, reps, out, cyc);
         run<10, 8>("chain + 8 v_cndmask", w, reps, out, cyc);
+        run<11, 0>("bf16 32x32x16 dependent chain", w, reps, out, cyc);
+        run<12, 0>("bf16 two alternating chains", w, reps, out, cyc);
+        run<13, 4>("bf16 chain + 4 v_fma_f32", w, reps, out, cyc);
+        run<13, 8>("bf16 chain + 8 v_fma_f32", w, reps, out, cyc);
+        run<14, 4>("bf16 chain + 4 v_and_b32", w, reps, out, cyc);
+        run<14, 8>("bf16 chain + 8 v_and_b32", w, reps, out, cyc);
+        run<14, 16>("bf16 chain + 16 v_and_b32", w, reps, out, cyc);
+        run<15, 8>("bf16 two chains + 8 v_and_b32", w, reps, out, cyc);
         run<5, 2>("chain + 2 ds_read_b32 + wait", w, reps, out, cyc);
         run<5, 4>("chain + 4 ds_read_b32 + wait", w, reps, out, cyc);
     }
