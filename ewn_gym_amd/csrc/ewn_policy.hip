@@ -5,6 +5,7 @@
 #include "ewn_policy.hpp"
 #include "ewn_a2c.hpp"
 #include "ewn_a2c2.hpp"
+#include "ewn_a2c3.hpp"
 
 // which instantiation serves the configuration: opp 0 minimax (table image, max_depth 1-4), 1 RandomAgent
 static int policy_plan(const ewn_config *cfg, const Geom &g, int &opp)
@@ -119,7 +120,7 @@ int64_t ewn_a2c_scratch_bytes(const ewn_config *cfg, int K)
     return ((int64_t)K * k.N + (int64_t)A2C_MAX_BLOCKS * (P + 8) + 64) * 4;
 }
 
-// 5x5: two waves per tile (k_a2c_grad2); EWN_A2C_TEAM=0 selects the one-wave-per-tile kernel (A/B measurements)
+// 5x5, f32 MFMA: two waves per tile (k_a2c_grad2)
 static int a2c_grad_launch_team(const A2cCfg &ac, A2cBuf ab, float *grad, hipStream_t s)
 {
     constexpr size_t lds = A2c2Geo<5>::lds_bytes();
@@ -136,11 +137,32 @@ static int a2c_grad_launch_team(const A2cCfg &ac, A2cBuf ab, float *grad, hipStr
     return launch_status();
 }
 
+// the bf16 x 3 kernel (ewn_a2c3.hpp): one wave per tile and SIMD, everything in registers
+template <int S>
+static int a2c_grad_launch_b3(const A2cCfg &ac, A2cBuf ab, float *grad, hipStream_t s)
+{
+    constexpr size_t lds = A2c3Geo<S>::lds_bytes();
+    static_assert(lds <= 160 * 1024, "weight images + the gradient image must fit the CU's LDS");
+    auto kv = k_a2c_grad3<S, 1>;
+    auto kp = k_a2c_grad3<S, 0>;
+    if (hipFuncSetAttribute((const void *)kv, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return EWN_ELAUNCH;
+    if (hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return EWN_ELAUNCH;
+    const int blocks = a2c_blocks(ac.N, 4);
+    kv<<<blocks, 256, lds, s>>>(ac, ab);         // value pass first: it leaves the advantages for the policy pass
+    kp<<<blocks, 256, lds, s>>>(ac, ab);
+    A2cRedBuf rb = { ab.partial, ab.stats, grad, blocks, MlpGeo<S>::P };
+    k_a2c_reduce<<<(MlpGeo<S>::P + 8 + A2C_RED_E - 1) / A2C_RED_E, 256, 0, s>>>(rb);
+    return launch_status();
+}
+
+// EWN_A2C_KERNEL: 3 (default) the bf16 x 3 register kernel; 2 the f32-MFMA team kernel (5x5); 1 the f32-MFMA one-wave kernel -- the
+// older two stay for A/B measurements and as independent implementations the tests compare
 template <int S>
 static int a2c_grad_launch(const A2cCfg &ac, A2cBuf ab, float *grad, hipStream_t s)
 {
-    static const bool team = [] { const char *e = getenv("EWN_A2C_TEAM"); return e ? atoi(e) != 0 : true; }();
-    if (S == 5 && team) return a2c_grad_launch_team(ac, ab, grad, s);
+    static const int kind = [] { const char *e = getenv("EWN_A2C_KERNEL"); return e ? atoi(e) : 3; }();
+    if (kind >= 3 || kind <= 0) return a2c_grad_launch_b3<S>(ac, ab, grad, s);
+    if (S == 5 && kind == 2) return a2c_grad_launch_team(ac, ab, grad, s);
     constexpr int NWV = A2cWaves<S>::N;
     constexpr size_t lds = a2c_lds_bytes<S, NWV>();
     static_assert(lds <= 160 * 1024, "the gradient kernel's images and transpose tiles must fit the CU's LDS");
