@@ -15,6 +15,9 @@ OBJ = os.path.join(HERE, "lib", "obj")
 # -ffp-contract=off: the fp64 heuristic and expectation sums must round exactly like the
 # reference's Python floats (no FMA contraction); no fast-math anywhere.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
+# per translation unit.  ewn_policy.hip: no SLP vectorisation -- it turns pairs of fp32 operations into packed-fp32 instructions
+# (v_pk_add_f32 ...), which measured (tools/mfma_probe.hip) do not overlap with the bf16 matrix pipe the way plain VALU work does
+FILE_FLAGS = {"ewn_policy.hip": ["-fno-slp-vectorize"]}
 
 
 def stale():
@@ -33,7 +36,7 @@ def build(force=False, verbose=False):
     jobs = []
     for src in SRC:
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
-        cmd = [hipcc] + FLAGS + extra + ["-c", "-o", obj, src]
+        cmd = [hipcc] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + extra + ["-c", "-o", obj, src]
         if verbose:
             print(" ".join(cmd), flush=True)
         jobs.append((subprocess.Popen(cmd), obj, cmd))

@@ -29,6 +29,13 @@ template <int S> struct A2c3Geo {
 };
 
 #define A2C3_FENCE() __builtin_amdgcn_sched_barrier(0)
+// -DA2C3_STAMPS: shader-clock time per region of the step (block 0, wave 0), left in the 64 spare floats behind the scratch's stats
+// (diagnostic build only: every stamp waits for the LDS queue)
+#ifdef A2C3_STAMPS
+#define A2C3_T(i) do { const u64 now_ = __builtin_amdgcn_s_memtime(); tacc[i] += (u32)(now_ - tlast); tlast = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define A2C3_T(i) do { } while (0)
+#endif
 
 // identity operands: slot jj of lane (n, h) is 1.0 where the slot's k is column n
 EWN_DEV u32x4 a2c3_identity(int lane, bool unit_slots, int c)
@@ -65,6 +72,24 @@ EWN_DEV A2c3Ld<S> a2c3_load(const A2cCfg &c, const A2cBuf &B, int t, int gc, int
     if (t < c.K) L.in = a2c_step_in<NET>(c, B, rrow + (size_t)c.N * STR, CELLS, t, gc);   // row t + 1: action a_t, flags of step t
     else L.in = A2cStepIn{ 0, 0, false, 0.0f, 0.0f };
     return L;
+}
+
+// features: record bytes 16 kb + 8 h .. + 7 of my sample (bytes past the board masked off), the dice one-hot
+template <int S>
+EWN_DEV void a2c3_features(const A2c3Ld<S> &L, int h, u32x4 (&xop)[Mlp3Geo<S>::KB1])
+{
+    constexpr int CELLS = S * S;
+    #pragma unroll
+    for (int kb = 0; kb < Mlp3Geo<S>::KB1; kb++) {
+        u32 lo = L.xb[kb].x, hi = L.xb[kb].y;
+        if (16 * kb + 15 >= CELLS) {
+            const int nv = CELLS - 16 * kb - 8 * h;                      // valid bytes of my eight
+            const unsigned long long m = nv >= 8 ? ~0ull : (nv <= 0 ? 0ull : ((1ull << (8 * nv)) - 1ull));
+            lo &= (u32)m; hi &= (u32)(m >> 32);
+        }
+        xop[kb] = mlp3_bytes_operand(lo, hi);
+        if (16 * kb + 15 >= CELLS && 16 * kb < CELLS + 7) xop[kb] = mlp3_onehot(xop[kb], CELLS + L.dice - 1 - (16 * kb + 8 * h));
+    }
 }
 
 // NET 0: policy body + action head; NET 1: value body + value head.  256 threads: four waves, one per SIMD.
@@ -128,6 +153,10 @@ __global__ __launch_bounds__(256, 1) void k_a2c_grad3(A2cCfg c, A2cBuf B)
     float dbh[MLP_NA] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
     float st_pl = 0.0f, st_vl = 0.0f, st_en = 0.0f;
 
+#ifdef A2C3_STAMPS
+    u32 tacc[16] = { 0 };
+    u64 tlast = __builtin_amdgcn_s_memtime();
+#endif
     const int tiles = (c.N + 31) / 32;
     #pragma unroll 1
     for (int tile = (int)blockIdx.x * NWV + wave; tile < tiles; tile += (int)gridDim.x * NWV) {
@@ -135,72 +164,90 @@ __global__ __launch_bounds__(256, 1) void k_a2c_grad3(A2cCfg c, A2cBuf B)
         const bool valid = game < c.N;
         const int gc = valid ? game : c.N - 1;
         float Rn = 0.0f;
-        const int t0 = NET ? c.K : c.K - 1;
-        A2c3Ld<S> cur = a2c3_load<S, NET>(c, B, t0, gc, h);
-        // t = K: the bootstrap value V(s_K) (value pass only); t = K-1 .. 0: forward + backward of step t
-        #pragma unroll 1
-        for (int t = t0; t >= 0; t--) {
-            const A2c3Ld<S> nxt = a2c3_load<S, NET>(c, B, t > 0 ? t - 1 : 0, gc, h);
-            // ---- features: record bytes 16 kb + 8 h .. + 7 of my sample (bytes past the board masked off), the dice one-hot
+        A2c3Ld<S> cur = a2c3_load<S, NET>(c, B, NET ? c.K : c.K - 1, gc, h);
+        if constexpr (NET == 1) {       // the bootstrap value V(s_K): a forward pass of its own (the step loop below stays branch-free)
+            const A2c3Ld<S> nxt = a2c3_load<S, NET>(c, B, c.K - 1, gc, h);
             u32x4 xop[KB1];
-            #pragma unroll
-            for (int kb = 0; kb < KB1; kb++) {
-                u32 lo = cur.xb[kb].x, hi = cur.xb[kb].y;
-                if (16 * kb + 15 >= CELLS) {
-                    const int nv = CELLS - 16 * kb - 8 * h;                      // valid bytes of my eight
-                    const unsigned long long m = nv >= 8 ? ~0ull : (nv <= 0 ? 0ull : ((1ull << (8 * nv)) - 1ull));
-                    lo &= (u32)m; hi &= (u32)(m >> 32);
-                }
-                xop[kb] = mlp3_bytes_operand(lo, hi);
-                if (16 * kb + 15 >= CELLS && 16 * kb < CELLS + 7) xop[kb] = mlp3_onehot(xop[kb], CELLS + cur.dice - 1 - (16 * kb + 8 * h));
-            }
-            // The phases below are fenced (A2C3_FENCE): a lone wave per SIMD has 256 architectural registers for everything the VALU
-            // touches, and an unfenced schedule hoists every phase's operand loads and splits to the top (measured: 300 registers
-            // spilled to scratch, 27 us per tile and step).  Inside a phase the k-blocks stream: split eight registers, issue their
-            // MFMAs, move on -- an operand lives for one k-block, results wait in the accumulation registers.
-            // ---- layer 1
+            a2c3_features<S>(cur, h, xop);
             f32x16 h1[2], h2[2];
+            float out[1];
+            mlp3_forward<S, 1>(img, lane, [&](int kb) { return xop[kb]; }, h1, h2, out);
+            Rn = out[0];
+            cur = nxt;
+            A2C3_FENCE();
+        }
+        // t = K-1 .. 0: forward + backward of step t
+        #pragma unroll 1
+        for (int t = c.K - 1; t >= 0; t--) {
+            const A2c3Ld<S> nxt = a2c3_load<S, NET>(c, B, t > 0 ? t - 1 : 0, gc, h);
+            // ---- layer 1's weight operands are asked for first: the feature decode below covers their LDS latency
+            Mlp3Op w1[2][KB1];
+            #pragma unroll
+            for (int kb = 0; kb < KB1; kb++) { w1[0][kb] = mlp3_load(I1, Q::N_W1, kb * 64 + lane); w1[1][kb] = mlp3_load(I1, Q::N_W1, (KB1 + kb) * 64 + lane); }
+            u32x4 xop[KB1];
+            a2c3_features<S>(cur, h, xop);
+            A2C3_FENCE();
+            A2C3_T(0);
+            // The step is a chain of fenced regions (A2C3_FENCE = sched_barrier).  Two reasons.  Registers: a lone wave per SIMD has 256
+            // architectural registers for everything the VALU touches, and an unfenced schedule hoists every operand load and split to
+            // the top (measured: 300 registers spilled to scratch, 27 us per tile and step).  Overlap: a wave issues in order, so its
+            // MFMAs run under its own VALU work only when the two alternate IN PROGRAM ORDER -- each region therefore pairs the MFMAs
+            // of one k-block with the operand split of the NEXT one (or of a later product), which do not depend on each other, and the
+            // scheduler interleaves inside the region.  An operand lives for one k-block; results wait in the accumulation registers.
+            // ---- layer 1 (layer 2's first weight operands are asked for under it)
+            f32x16 h1[2], h2[2];
+            Mlp3Op wa = mlp3_load(I2, Q::N_W2, lane), wb = mlp3_load(I2, Q::N_W2, 4 * 64 + lane);
             {
                 f32x16 a0 = mlp_bias_acc(Lf + Q::F_B1, h), a1 = mlp_bias_acc(Lf + Q::F_B1 + 32, h);
                 #pragma unroll
-                for (int kb = 0; kb < KB1; kb++) {
-                    a0 = mlp3_mac_ax(a0, mlp3_load(I1, Q::N_W1, kb * 64 + lane), xop[kb]);
-                    a1 = mlp3_mac_ax(a1, mlp3_load(I1, Q::N_W1, (KB1 + kb) * 64 + lane), xop[kb]);
-                }
+                for (int kb = 0; kb < KB1; kb++) { a0 = mlp3_mac_ax(a0, w1[0][kb], xop[kb]); a1 = mlp3_mac_ax(a1, w1[1][kb], xop[kb]); }
                 h1[0] = mlp_tanh16(a0); h1[1] = mlp_tanh16(a1);
             }
-            A2C3_FENCE();
             // ---- layer 2, and h1 in U-layout for the backward pass (the same operand, times the identity)
             f32x16 h1U[2] = { (f32x16)(0.0f), (f32x16)(0.0f) };
+            Mlp3Op wf = wa;                                // the MFMA head's / dh2's first weight operand, asked for a region ahead
             {
                 f32x16 c0 = mlp_bias_acc(Lf + Q::F_B2, h), c1 = mlp_bias_acc(Lf + Q::F_B2 + 32, h);
+                Mlp3Op u = mlp3_operand(h1[0], 0);
+                A2C3_FENCE();
+                A2C3_T(1);
                 #pragma unroll
                 for (int kb = 0; kb < 4; kb++) {
-                    const Mlp3Op u = mlp3_operand(h1[kb >> 1], kb & 1);
-                    c0 = mlp3_mac(c0, mlp3_load(I2, Q::N_W2, kb * 64 + lane), u);
-                    c1 = mlp3_mac(c1, mlp3_load(I2, Q::N_W2, (4 + kb) * 64 + lane), u);
-                    if (!(NET == 1 && t == c.K)) h1U[kb >> 1] = a2c3_transpose_add(h1U[kb >> 1], u, idu[kb & 1]);
+                    Mlp3Op un = u, wan = wa, wbn = wb;
+                    if (kb + 1 < 4) { wan = mlp3_load(I2, Q::N_W2, (kb + 1) * 64 + lane); wbn = mlp3_load(I2, Q::N_W2, (4 + kb + 1) * 64 + lane); }
+                    else if (NET == 0) wf = mlp3_load(IWF, A::N_WF, lane);
+                    if (kb + 1 < 4) un = mlp3_operand(h1[(kb + 1) >> 1], (kb + 1) & 1);
+                    c0 = mlp3_mac(c0, wa, u);
+                    c1 = mlp3_mac(c1, wb, u);
+                    h1U[kb >> 1] = a2c3_transpose_add(h1U[kb >> 1], u, idu[kb & 1]);
                     A2C3_FENCE();
+                    u = un; wa = wan; wb = wbn;
                 }
+                A2C3_T(2);
                 h2[0] = mlp_tanh16(c0); h2[1] = mlp_tanh16(c1);
             }
-            A2C3_FENCE();
             // ---- the head
             float out[NOUT];
             f32x16 h2U[2] = { (f32x16)(0.0f), (f32x16)(0.0f) };
             if constexpr (NET == 1) {
                 mlp3_head<S, 1>(img, lane, h2, out);
-                if (t == c.K) { Rn = out[0]; cur = nxt; continue; }   // V(s_K): the bootstrap value
+                A2C3_T(3);
             } else {
                 // the five logits as rows 0-4 of an MFMA tile (h2's operand split is needed for its U-layout anyway)
                 f32x16 lg = (f32x16)(0.0f);
+                Mlp3Op u = mlp3_operand(h2[0], 0);
+                A2C3_FENCE();
+                A2C3_T(3);
                 #pragma unroll
                 for (int kb = 0; kb < 4; kb++) {
-                    const Mlp3Op u = mlp3_operand(h2[kb >> 1], kb & 1);
-                    lg = mlp3_mac(lg, mlp3_load(IWF, A::N_WF, kb * 64 + lane), u);
+                    Mlp3Op un = u, wfn = wf;
+                    if (kb + 1 < 4) { wfn = mlp3_load(IWF, A::N_WF, (kb + 1) * 64 + lane); un = mlp3_operand(h2[(kb + 1) >> 1], (kb + 1) & 1); }
+                    lg = mlp3_mac(lg, wf, u);
                     h2U[kb >> 1] = a2c3_transpose_add(h2U[kb >> 1], u, idu[kb & 1]);
                     A2C3_FENCE();
+                    u = un; wf = wfn;
                 }
+                A2C3_T(4);
                 // rows 0-3 sit in registers 0-3 of lane half 0, row 4 in register 0 of half 1
                 const float o0 = mlp_other_half(lg[0], lane), o1 = mlp_other_half(lg[1], lane), o2 = mlp_other_half(lg[2], lane), o3 = mlp_other_half(lg[3], lane);
                 out[0] = (h ? o0 : lg[0]) + Lf[Q::F_BH]; out[1] = (h ? o1 : lg[1]) + Lf[Q::F_BH + 1];
@@ -208,7 +255,10 @@ __global__ __launch_bounds__(256, 1) void k_a2c_grad3(A2cCfg c, A2cBuf B)
                 out[4] = (h ? lg[0] : o0) + Lf[Q::F_BH + 4];
             }
             A2C3_FENCE();
-            // ---- the loss of step t and its gradient w.r.t. the head outputs (both lane halves hold the same numbers)
+            A2C3_T(5);
+            // ---- the loss of step t and its gradient w.r.t. the head outputs (both lane halves hold the same numbers); dh2's weight
+            // operands are asked for under it
+            const Mlp3Op wh0 = mlp3_load(IWH, A::N_WH, lane), wh1 = mlp3_load(IWH, A::N_WH, 64 + lane);
             float d[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
             a2c_loss_grad<NET>(c, B, cur.in, t, game, valid, h == 0, out, Rn, d, st_pl, st_vl, st_en);
             Mlp3Op dop;                              // d as a k-block: slot (h, jj) = head row 8 h + jj
@@ -219,46 +269,66 @@ __global__ __launch_bounds__(256, 1) void k_a2c_grad3(A2cCfg c, A2cBuf B)
                 dop = mlp3_operand(v);
             }
             A2C3_FENCE();
-            // ---- head gradients
-            if constexpr (NET == 1) {
-                #pragma unroll
-                for (int mt = 0; mt < 2; mt++) {
+            A2C3_T(6);
+            // ---- dh2 = Wh^T d (S-layout) and d in U-layout on the matrix pipe, under them the first splits of h2 in U-layout (policy) /
+            // the value head's gradient (value)
+            f32x16 g2[2], dU = (f32x16)(0.0f);
+            Mlp3Op h2k[2][2];                        // [unit tile][sample k-block]
+            {
+                g2[0] = mlp3_mac((f32x16)(0.0f), wh0, dop); g2[1] = mlp3_mac((f32x16)(0.0f), wh1, dop);
+                if constexpr (NET == 0) {
+                    dU = a2c3_transpose_add(dU, dop, idf[0]);
                     #pragma unroll
-                    for (int r = 0; r < 16; r++) dWh[mt][r] += d[0] * h2[mt][r];     // per-lane partial of dWv[unit] = sum_s dV_s h2[unit][s]
-                }
-                if (h == 0) dbh[0] += d[0];
-            } else {
-                // dWa[a][unit] = sum_s d[a][s] h2[unit][s]: both operands in U-layout (d: head row on the lane)
-                const f32x16 dU = a2c3_transpose_add((f32x16)(0.0f), dop, idf[0]);
-                const Mlp3Op dk[2] = { mlp3_operand(dU, 0), mlp3_operand(dU, 1) };
-                #pragma unroll
-                for (int nt = 0; nt < 2; nt++) {
+                    for (int nt = 0; nt < 2; nt++) { h2k[nt][0] = mlp3_operand(h2U[nt], 0); h2k[nt][1] = mlp3_operand(h2U[nt], 1); }
+                    if (h == 0) { for (int i = 0; i < 5; i++) dbh[i] += d[i]; }
+                } else {
                     #pragma unroll
-                    for (int kb = 0; kb < 2; kb++) dWh[nt] = mlp3_mac(dWh[nt], dk[kb], mlp3_operand(h2U[nt], kb));
-                    A2C3_FENCE();
+                    for (int mt = 0; mt < 2; mt++) {
+                        #pragma unroll
+                        for (int r = 0; r < 16; r++) dWh[mt][r] += d[0] * h2[mt][r];     // per-lane partial of dWv[unit] = sum_s dV_s h2[unit][s]
+                    }
+                    if (h == 0) dbh[0] += d[0];
                 }
-                if (h == 0) { for (int i = 0; i < 5; i++) dbh[i] += d[i]; }
             }
             A2C3_FENCE();
-            // ---- dh2 = Wh^T d, g2 = dh2 (1 - h2^2)   (S-layout)
-            f32x16 g2[2];
+            A2C3_T(7);
+            // g2 = dh2 (1 - h2^2)
             #pragma unroll
             for (int mt = 0; mt < 2; mt++) {
-                g2[mt] = mlp3_mac((f32x16)(0.0f), mlp3_load(IWH, A::N_WH, mt * 64 + lane), dop);
                 #pragma unroll
                 for (int r = 0; r < 16; r++) g2[mt][r] *= 1.0f - h2[mt][r] * h2[mt][r];
             }
+            Mlp3Op dk[2];
+            if constexpr (NET == 0) { dk[0] = mlp3_operand(dU, 0); dk[1] = mlp3_operand(dU, 1); }
+            Mlp3Op wt0 = mlp3_load(IW2T, A::N_W2T, lane), wt1 = mlp3_load(IW2T, A::N_W2T, 4 * 64 + lane);   // dh1's first weight operands
             A2C3_FENCE();
-            // ---- g2 in U-layout; dh1 = W2^T g2 computed in U-layout directly (operands swapped); g1 = dh1 (1 - h1^2)
+            A2C3_T(8);
+            // ---- g2 in U-layout; dh1 = W2^T g2 computed in U-layout directly (operands swapped); the action head's gradient
+            // dWa[a][unit] = sum_s d[a][s] h2[unit][s] (both operands in U-layout; d: head row on the lane); under them the splits of h1
+            // in U-layout that dW2 wants
             f32x16 g2U[2] = { (f32x16)(0.0f), (f32x16)(0.0f) }, g1U[2] = { (f32x16)(0.0f), (f32x16)(0.0f) };
-            #pragma unroll
-            for (int kb = 0; kb < 4; kb++) {
-                const Mlp3Op u = mlp3_operand(g2[kb >> 1], kb & 1);
-                g2U[kb >> 1] = a2c3_transpose_add(g2U[kb >> 1], u, idu[kb & 1]);
-                #pragma unroll
-                for (int nt = 0; nt < 2; nt++) g1U[nt] = mlp3_mac(g1U[nt], u, mlp3_load(IW2T, A::N_W2T, (nt * 4 + kb) * 64 + lane));
+            Mlp3Op h1k[2][2];                        // [unit tile][sample k-block]
+            {
+                Mlp3Op u = mlp3_operand(g2[0], 0);
                 A2C3_FENCE();
+                A2C3_T(9);
+                #pragma unroll
+                for (int kb = 0; kb < 4; kb++) {
+                    Mlp3Op un = u, wt0n = wt0, wt1n = wt1;
+                    if (kb + 1 < 4) {
+                        wt0n = mlp3_load(IW2T, A::N_W2T, (kb + 1) * 64 + lane); wt1n = mlp3_load(IW2T, A::N_W2T, (4 + kb + 1) * 64 + lane);
+                        un = mlp3_operand(g2[(kb + 1) >> 1], (kb + 1) & 1);
+                    }
+                    h1k[kb >> 1][kb & 1] = mlp3_operand(h1U[kb >> 1], kb & 1);
+                    g2U[kb >> 1] = a2c3_transpose_add(g2U[kb >> 1], u, idu[kb & 1]);
+                    g1U[0] = mlp3_mac(g1U[0], u, wt0); g1U[1] = mlp3_mac(g1U[1], u, wt1);
+                    if constexpr (NET == 0) dWh[kb >> 1] = mlp3_mac(dWh[kb >> 1], dk[kb & 1], h2k[kb >> 1][kb & 1]);
+                    A2C3_FENCE();
+                    u = un; wt0 = wt0n; wt1 = wt1n;
+                }
+                A2C3_T(10);
             }
+            // g1 = dh1 (1 - h1^2); db2 = the sum of g2 over the samples
             #pragma unroll
             for (int nt = 0; nt < 2; nt++) {
                 float sb = 0.0f;
@@ -267,33 +337,50 @@ __global__ __launch_bounds__(256, 1) void k_a2c_grad3(A2cCfg c, A2cBuf B)
                 db2a[nt] += sb;
             }
             A2C3_FENCE();
-            // ---- dW2 += g2 . h1^T
-            #pragma unroll
-            for (int kb = 0; kb < 2; kb++) {
-                const Mlp3Op ka[2] = { mlp3_operand(g2U[0], kb), mlp3_operand(g2U[1], kb) };
-                const Mlp3Op kv[2] = { mlp3_operand(h1U[0], kb), mlp3_operand(h1U[1], kb) };
-                #pragma unroll
-                for (int mt = 0; mt < 2; mt++) {
-                    #pragma unroll
-                    for (int nt = 0; nt < 2; nt++) dW2[mt][nt] = mlp3_mac(dW2[mt][nt], ka[mt], kv[nt]);
-                }
+            A2C3_T(11);
+            // ---- dW2 += g2 . h1^T, then dW1 += g1 . x^T (the bias gradient db1 is the sum of its seven one-hot dice columns: taken
+            // at the end); under dW2's MFMAs the splits of g1 and the features in U-layout
+            {
+                Mlp3Op ka[2] = { mlp3_operand(g2U[0], 0), mlp3_operand(g2U[1], 0) };
+                Mlp3Op g1k[2][2];
+                f32x16 xU[FT];
                 A2C3_FENCE();
-            }
-            // ---- dW1 += g1 . x^T (the bias gradient db1 is the sum of its seven one-hot dice columns: taken at the end)
-            #pragma unroll
-            for (int ft = 0; ft < FT; ft++) {
-                f32x16 xU = (f32x16)(0.0f);                  // features 32 ft + n of the tile's samples (small integers: one bf16 part)
-                #pragma unroll
-                for (int cc = 0; cc < 2; cc++) { if (2 * ft + cc < KB1) xU = MLP3_MFMA(xop[2 * ft + cc], idf[cc], xU); }
+                A2C3_T(12);
                 #pragma unroll
                 for (int kb = 0; kb < 2; kb++) {
-                    u32x4 xk;
+                    Mlp3Op kan[2] = { ka[0], ka[1] };
+                    if (kb == 0) { kan[0] = mlp3_operand(g2U[0], 1); kan[1] = mlp3_operand(g2U[1], 1); }
+                    g1k[0][kb] = mlp3_operand(g1U[0], kb); g1k[1][kb] = mlp3_operand(g1U[1], kb);
+                    if (kb == 0) {
+                        #pragma unroll
+                        for (int ft = 0; ft < FT; ft++) {    // features 32 ft + n of the tile's samples (small integers: one bf16 part)
+                            xU[ft] = (f32x16)(0.0f);
+                            #pragma unroll
+                            for (int cc = 0; cc < 2; cc++) { if (2 * ft + cc < KB1) xU[ft] = MLP3_MFMA(xop[2 * ft + cc], idf[cc], xU[ft]); }
+                        }
+                    }
                     #pragma unroll
-                    for (int q = 0; q < 4; q++) xk[q] = mlp3_pack(__float_as_uint(xU[8 * kb + 2 * q]), __float_as_uint(xU[8 * kb + 2 * q + 1]));
-                    #pragma unroll
-                    for (int mt = 0; mt < 2; mt++) dW1[mt][ft] = mlp3_mac_ax(dW1[mt][ft], mlp3_operand(g1U[mt], kb), xk);
+                    for (int mt = 0; mt < 2; mt++) {
+                        #pragma unroll
+                        for (int nt = 0; nt < 2; nt++) dW2[mt][nt] = mlp3_mac(dW2[mt][nt], ka[mt], h1k[nt][kb]);
+                    }
                     A2C3_FENCE();
+                    ka[0] = kan[0]; ka[1] = kan[1];
                 }
+                A2C3_T(13);
+                #pragma unroll
+                for (int ft = 0; ft < FT; ft++) {
+                    #pragma unroll
+                    for (int kb = 0; kb < 2; kb++) {
+                        u32x4 xk;
+                        #pragma unroll
+                        for (int q = 0; q < 4; q++) xk[q] = mlp3_pack(__float_as_uint(xU[ft][8 * kb + 2 * q]), __float_as_uint(xU[ft][8 * kb + 2 * q + 1]));
+                        #pragma unroll
+                        for (int mt = 0; mt < 2; mt++) dW1[mt][ft] = mlp3_mac_ax(dW1[mt][ft], g1k[mt][kb], xk);
+                    }
+                }
+                A2C3_FENCE();
+                A2C3_T(14);
             }
             cur = nxt;
         }
@@ -365,4 +452,7 @@ __global__ __launch_bounds__(256, 1) void k_a2c_grad3(A2cCfg c, A2cBuf B)
     for (int e = threadIdx.x; e < G::BODY; e += NT) dst[o_body + e] = GI[e];
     for (int e = threadIdx.x; e < NOUT * MLP_H + NOUT; e += NT) dst[o_hw + e] = GI[I_WH + e];   // head W then b: contiguous in both layouts
     if (threadIdx.x < 4) B.stats[((size_t)blockIdx.x * 2 + NET) * 4 + threadIdx.x] = GI[I_END + threadIdx.x];
+#ifdef A2C3_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) { for (int i = 0; i < 16; i++) B.stats[256 * 8 + NET * 16 + i] = (float)tacc[i]; }
+#endif
 }

@@ -52,7 +52,11 @@ EWN_DEV u32 mlp3_pack(u32 a, u32 b) { return __builtin_amdgcn_perm(b, a, 0x07060
 
 struct Mlp3Op { u32x4 p[3]; };             // one k-block of a three-part operand
 
-// eight fp32 values -> the three operand parts
+// eight fp32 values -> the three operand parts: per value two ANDs and two subtractions, per pair and part one v_perm_b32 that picks
+// the top halves straight into an operand register (5.5 instructions per value).  NOT the packed-fp32 subtraction (v_pk_add_f32, two
+// values per issue slot): measured (tools/mfma_probe.hip) packed fp32 arithmetic does not run beside the matrix pipe -- eight of them
+// behind a bf16 MFMA take 86 cycles against 46 for eight v_and_b32 -- and running beside it is the whole point (the translation
+// unit is built with -fno-slp-vectorize for the same reason)
 EWN_DEV Mlp3Op mlp3_operand(const float (&v)[8])
 {
     u32 q[3][8];

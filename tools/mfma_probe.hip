@@ -14,6 +14,9 @@ typedef unsigned long long u64;
 
 #define MF(acc) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 #define MB(acc) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a8), "v"(b8))
+#define MBA(acc) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a8), "v"(b8))
+#define VP(x) asm volatile("v_perm_b32 %0, %0, %1, %1" : "+v"(x) : "v"(a))
+#define VK(x, y) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(x) : "v"(y))
 #define VF(x) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x) : "v"(a))
 #define LR(x) asm volatile("ds_read_b32 %0, %1" : "=v"(x) : "v"(ldsaddr))
 #define VI(x) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x) : "v"(a))
@@ -32,6 +35,9 @@ __global__ void probe(float *out, u64 *cyc, int reps)
     for (int i = 0; i < 8; i++) { a8[i] = (short)(0x3f80 + threadIdx.x % 3); b8[i] = (short)0x3f00; }
     float f[16];
     for (int i = 0; i < 16; i++) f[i] = (float)i;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 d2[8];
+    for (int i = 0; i < 8; i++) { d2[i][0] = (float)i; d2[i][1] = 1.0f; }
     sm[threadIdx.x] = 1.0f;
     __syncthreads();
     const unsigned ldsaddr = (threadIdx.x & 63) * 4;
@@ -62,13 +68,18 @@ __global__ void probe(float *out, u64 *cyc, int reps)
             if (MODE == 13) { MB(c0); _Pragma("unroll") for (int i = 0; i < NF; i++) VF(f[i & 15]); }   // ... chain + fp32 VALU fillers
             if (MODE == 14) { MB(c0); _Pragma("unroll") for (int i = 0; i < NF; i++) VI(f[i & 15]); }   // ... chain + integer VALU fillers
             if (MODE == 15) { if (k & 1) MB(c1); else MB(c0); _Pragma("unroll") for (int i = 0; i < NF; i++) VI(f[i & 15]); }
+            if (MODE == 16) { MBA(c0); _Pragma("unroll") for (int i = 0; i < NF; i++) VI(f[i & 15]); }   // accumulator in AGPRs + integer VALU
+            if (MODE == 17) { MB(c0); _Pragma("unroll") for (int i = 0; i < NF; i++) VP(f[i & 15]); }    // v_perm_b32 fillers
+            if (MODE == 18) { MB(c0); _Pragma("unroll") for (int i = 0; i < NF; i++) VK(d2[i & 7], d2[(i + 1) & 7]); }   // v_pk_add_f32 fillers
+            if (MODE == 19) { _Pragma("unroll") for (int i = 0; i < NF; i++) VK(d2[i & 7], d2[(i + 1) & 7]); }
+            if (MODE == 20) { _Pragma("unroll") for (int i = 0; i < NF; i++) VP(f[i & 15]); }
             if (MODE == 10) { MF(c0); _Pragma("unroll") for (int i = 0; i < NF; i++) VC(f[i & 15]); }
         }
     }
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15");
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
     float s = 0.0f;
-    for (int i = 0; i < 16; i++) s += c0[i] + c1[i] + f[i];
+    for (int i = 0; i < 16; i++) s += c0[i] + c1[i] + f[i] + d2[i & 7][i >> 3];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)] = t1 - t0;
 }
@@ -122,6 +133,12 @@ int main(int argc, char **argv)
         run<14, 8>("bf16 chain + 8 v_and_b32", w, reps, out, cyc);
         run<14, 16>("bf16 chain + 16 v_and_b32", w, reps, out, cyc);
         run<15, 8>("bf16 two chains + 8 v_and_b32", w, reps, out, cyc);
+        run<16, 8>("bf16 chain (AGPR acc) + 8 v_and_b32", w, reps, out, cyc);
+        run<16, 16>("bf16 chain (AGPR acc) + 16 v_and_b32", w, reps, out, cyc);
+        run<17, 8>("bf16 chain + 8 v_perm_b32", w, reps, out, cyc);
+        run<20, 8>("8 v_perm_b32 only", w, reps, out, cyc);
+        run<18, 8>("bf16 chain + 8 v_pk_add_f32", w, reps, out, cyc);
+        run<19, 8>("8 v_pk_add_f32 only", w, reps, out, cyc);
         run<5, 2>("chain + 2 ds_read_b32 + wait", w, reps, out, cyc);
         run<5, 4>("chain + 4 ds_read_b32 + wait", w, reps, out, cyc);
     }
