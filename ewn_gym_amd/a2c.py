@@ -89,9 +89,11 @@ class ActorCritic(nn.Module):
         assert off == flat.numel()
 
     def features(self, board, dice):
-        """board int8 [N,S,S], dice int8 [N] (1..cube_num) -> float32 [N, S*S + cube_num + 1]"""
-        b = board.reshape(board.shape[0], -1).to(torch.float32)
-        oh = torch.nn.functional.one_hot((dice.to(torch.int64) - 1).clamp_(0, self.cube_num), self.cube_num + 1).to(torch.float32)
+        """board int8 [N,S,S], dice int8 [N] (1..cube_num) -> [N, S*S + cube_num + 1] in the parameters' dtype (float32; float64 when
+        the model was cast for a reference evaluation, tools/a2c_accuracy.py)"""
+        dt = self.value_net.weight.dtype
+        b = board.reshape(board.shape[0], -1).to(dt)
+        oh = torch.nn.functional.one_hot((dice.to(torch.int64) - 1).clamp_(0, self.cube_num), self.cube_num + 1).to(dt)
         return torch.cat([b, oh], dim=1)
 
     def forward(self, board, dice):

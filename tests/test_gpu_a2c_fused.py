@@ -137,3 +137,42 @@ def test_fused_trainer_learns_and_matches_the_torch_trainer_step(ea):
     last = tr.stats_dict()
     assert np.isfinite(last["loss"]) and last["grad_norm"] > 0
     assert last["mean_reward"] > first["mean_reward"] + 0.05, (first, last)
+
+
+def test_bf16x3_forward_and_gradient_are_fp32_accurate(ea):
+    """The network runs on the bf16 matrix pipe with every operand split into three bf16 parts (csrc/ewn_mlp3.hpp).  The claim is fp32
+    accuracy: against the same model evaluated in FLOAT64 the engine's logits and gradient must be as close as plain fp32 torch is
+    (measured, tools/a2c_accuracy.py: logits 6.9e-7 vs 1.0e-6, gradient 5.6e-8 vs 6.3e-8 relative)."""
+    import copy
+    from ewn_gym_amd._lib import EwnA2cHyper, check
+    from ewn_gym_amd.a2c import n_step_returns
+    from ewn_gym_amd.vec_env import _ptr, _stream
+    from tests.test_gpu_policy import make_model
+    N, S, K = 6000, 5, 5
+    env = ea.VecEWN(N, board_size=S, opponent_policy="minimax", max_depth=2, rng="philox", shaped=True, reward=10.0, illegal_move_tolerance=5,
+                    shaped_refresh_on_reset=True, autoreset=True, seed_stride=N, philox_key=23)
+    env.reset(seeds=(np.arange(N, dtype=np.uint64) + 5).astype(np.uint32))
+    model = make_model(S, 13, head_gain=1.0)
+    params = model.flat_parameters()
+    traj = env.alloc_rollout(K, layout="record", initial_obs=True)
+    logits = torch.zeros((K, N, 5), dtype=torch.float32, device="cuda")
+    for _ in range(3):
+        env.rollout_policy(K, params, traj=traj, noise_key=5, logits=logits)
+    gamma, vf_coef, ent_coef = 0.97, 0.5, 0.01
+    hp = EwnA2cHyper(gamma, vf_coef, ent_coef, 0.5, 7e-4, 0.99, 1e-5, 1)
+    scratch = torch.zeros(int(check(env.lib.ewn_a2c_scratch_bytes(C.byref(env.cfg), K))), dtype=torch.uint8, device="cuda")
+    grad = torch.zeros(params.numel() + 8, dtype=torch.float32, device="cuda")
+    check(env.lib.ewn_a2c_grad(C.byref(env.cfg), K, _ptr(traj["record"]), _ptr(traj["reward"]), _ptr(params), C.byref(hp), _ptr(grad),
+                               _ptr(scratch), _stream()), "ewn_a2c_grad")
+    m64 = copy.deepcopy(model).double()
+    obs_b, obs_d = traj["obs_board"], traj["obs_dice"]
+    with torch.no_grad():
+        l64 = torch.stack([torch.cat(m64(obs_b[t], obs_d[t])[:2], 1) for t in range(K)])
+        vals = torch.stack([m64(obs_b[t], obs_d[t])[2] for t in range(K)])
+        adv, ret = n_step_returns(traj["reward"].double(), vals, traj["terminated"].double(), m64(obs_b[K], obs_d[K])[2], gamma, 1.0)
+    logp, ent, value = m64.evaluate_actions(obs_b[:K].reshape(K * N, S, S), obs_d[:K].reshape(K * N), traj["action"].reshape(K * N, 2))
+    loss = -(adv.reshape(-1) * logp).mean() + vf_coef * torch.nn.functional.mse_loss(ret.reshape(-1), value) - ent_coef * ent.mean()
+    loss.backward()
+    g64 = torch.cat([p.grad.reshape(-1) for p in m64.parameters()])
+    assert float((logits.double() - l64).abs().max()) < 3e-6
+    assert float((grad[:-8].double() - g64).norm() / g64.norm()) < 5e-7
