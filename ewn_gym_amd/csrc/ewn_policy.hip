@@ -206,6 +206,8 @@ int ewn_a2c_apply(const ewn_config *cfg, float *params, float *sq_avg, const flo
     if (!params || !sq_avg || !grad || !hp) return EWN_ENULL;
     if (hp->world_size < 1) return EWN_EINVAL;
     A2cApplyCfg ac = { (int)ewn_policy_param_count(g.S, g.L), hp->learning_rate, hp->rms_alpha, hp->rms_eps, hp->max_grad_norm, 1.0f / (float)hp->world_size };
-    k_a2c_apply<<<1, 1024, 0, (hipStream_t)stream>>>(ac, params, sq_avg, grad, grad_norm_out);
+    const bool vec = ac.P <= 1024 * 4 * A2C_APPLY_V && ((uintptr_t)params | (uintptr_t)sq_avg | (uintptr_t)grad) % 16 == 0;
+    if (vec) k_a2c_apply_v4<<<1, 1024, 0, (hipStream_t)stream>>>(ac, params, sq_avg, grad, grad_norm_out);
+    else k_a2c_apply<<<1, 1024, 0, (hipStream_t)stream>>>(ac, params, sq_avg, grad, grad_norm_out);
     return launch_status();
 }

@@ -261,7 +261,8 @@ int ewn_step_k_policy(const ewn_config *cfg, const ewn_state *st, int K, const e
  * (n-step returns = GAE with lambda 1, no advantage normalisation; loss = policy gradient + vf_coef * MSE(returns, values) +
  * ent_coef * (-entropy), a mean over the n_steps x lanes batch; clip_grad_norm_(max_grad_norm); RMSprop(alpha, eps)).  SB3 is not
  * vendored: parity with it is unpinned, the arithmetic is checked against torch autograd of the same loss.  Forward (recomputed from
- * the records: the parameters have not changed since the rollout) and backward run on the matrix cores in exact fp32. */
+ * the records: the parameters have not changed since the rollout) and backward run on the bf16 matrix pipe with every operand split
+ * into three bf16 parts (six products per multiply: fp32 accuracy, measured against float64 -- tools/a2c_accuracy.py). */
 typedef struct ewn_a2c_hyper {
     float gamma;            /* 0.99 */
     float vf_coef;          /* 0.5 */
