@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/${1:-gpurun_out/r02p}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-COMMON="--no-cpu-baseline --no-extras"
+COMMON="--no-cpu-baseline --no-extras --no-spin"   # no clock warm-up launches under the profiler: they are the same kernel with fewer steps
 run_cfg() { # name, bench args...
   local name=$1; shift
   mkdir -p $OUT/$name
