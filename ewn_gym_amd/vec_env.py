@@ -210,6 +210,29 @@ class VecEWN:
                                   _stream()), "ewn_step_k")
         return self.board, self.dice
 
+    def bind_rollout(self, K, agent="random", agent_max_depth=3, traj=None, totals=None):
+        """rollout(K, ...) with its arguments marshalled ONCE: returns a zero-argument callable that enqueues the launch (for loops that
+        repeat the same call: one C-ABI call per invocation, a few microseconds of host time instead of the ~20 of building the structs).
+        The buffers of traj / totals must stay alive as long as the callable is used."""
+        traj, totals = traj or {}, totals or {}
+        for v in traj.values():
+            assert v.shape[0] >= K and v.shape[1] == self.N
+        col = (lambda k: None) if "record" in traj else traj.get
+        out = EwnRolloutOut(_ptr(col("board")), _ptr(col("dice")), _ptr(col("action")), _ptr(traj.get("reward")),
+                            _ptr(col("terminated")), _ptr(col("truncated")), _ptr(col("info")),
+                            _ptr(totals.get("return_sum")), _ptr(totals.get("n_steps")), _ptr(totals.get("n_episodes")),
+                            _ptr(totals.get("n_wins")), _ptr(traj.get("record")))
+        fn, cfg, st, outp = self.lib.ewn_step_k, C.byref(self.cfg), C.byref(self._st), C.byref(out)
+        k, a, d = int(K), AGENT[agent], int(agent_max_depth)
+        keep = (out, traj, totals)
+
+        def call():
+            rc = fn(cfg, st, k, a, d, outp, _stream())
+            if rc != 0:
+                check(rc, "ewn_step_k")
+            return keep and None
+        return call
+
     # -- K env steps per launch with the trained policy as the agent (ewn_step_k_policy; train.py:134, 148's rollout collection)
     def policy_param_count(self):
         return int(check(self.lib.ewn_policy_param_count(self.S, self.L), "ewn_policy_param_count"))

@@ -224,6 +224,20 @@ def test_rollout_slot_task_kernel_frozen_lanes_and_numpy_dice(ea):
     _rollout_vs_oracle(ea, 140000, 0, 200, 6, 2, opponent_policy="minimax", max_depth=5, rng="philox", philox_key=5, board_column=False)
 
 
+def test_bound_rollout_call_is_the_same_launch(ea):
+    """VecEWN.bind_rollout: the pre-marshalled call leaves the same state and trajectory as rollout()"""
+    outs = []
+    for bound in (False, True):
+        env = ea.VecEWN(SLOT_N, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=8, autoreset=True, seed_stride=SLOT_N)
+        env.reset(seeds=(np.arange(SLOT_N, dtype=np.uint64) + 5).astype(np.uint32))
+        traj = env.alloc_rollout(6, layout="record")
+        call = env.bind_rollout(6, traj=traj) if bound else (lambda: env.rollout(6, traj=traj))
+        call(); call()
+        outs.append((env.board.clone(), env.dice.clone(), traj["record"].clone(), traj["reward"].clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_config2_random_opponent_at_its_own_shape(ea):
     """BASELINE config 2 at its own shape (5x5, 65 536 lanes, RandomAgent opponent): ewn_step_k against the oracle on two slices,
     both trajectory layouts (the launcher's kernel choice depends on the lane count)"""

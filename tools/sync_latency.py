@@ -12,20 +12,34 @@ torch.cuda.synchronize()
 g = torch.cuda.CUDAGraph()
 with torch.cuda.graph(g):
     env.rollout(K, traj=traj)
-res = {"sync": [], "poll": [], "event_ms": []}
+bound = env.bind_rollout(K, traj=traj)      # the same launch as a direct C-ABI call with pre-marshalled arguments
+bound(); torch.cuda.synchronize()
+res = {"sync": [], "poll": [], "direct": [], "direct_noevents": [], "eager": [], "event_ms": [], "event_ms_direct": []}
 for rep in range(12):
-    for mode in ("sync", "poll"):
+    for mode in ("sync", "poll", "direct", "direct_noevents", "eager"):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        e0.record(); g.replay(); e1.record()
+        if mode == "direct_noevents":
+            bound()
+            torch.cuda.synchronize()
+            res[mode].append((time.perf_counter() - t0) * 1e6)
+            continue
+        e0.record()
+        if mode == "direct":
+            bound()
+        elif mode == "eager":
+            env.rollout(K, traj=traj)
+        else:
+            g.replay()
+        e1.record()
         if mode == "poll":
             while not e1.query():
                 pass
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         res[mode].append(dt * 1e6)
-        res["event_ms"].append(e0.elapsed_time(e1) * 1e3)
+        res["event_ms_direct" if mode in ("direct", "eager") else "event_ms"].append(e0.elapsed_time(e1) * 1e3)
 for k, v in res.items():
     v = sorted(v)
     print("%-9s median %.1f us  min %.1f  max %.1f" % (k, v[len(v) // 2], v[0], v[-1]))
