@@ -67,6 +67,10 @@ def parse():
                          "ewn_step's fused random_action output")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly from Python instead of replaying a hipGraph")
     ap.add_argument("--graph-steps", type=int, default=50, help="env steps captured per graph (step mode)")
+    ap.add_argument("--graph-rollout", action="store_true",
+                    help="rollout mode: replay a hipGraph of the ewn_step_k launch(es) instead of calling the C ABI directly.  A K-step launch "
+                         "is one long kernel: nothing to batch, and a graph launch costs the host more than the kernel launch it wraps "
+                         "(tools/sync_latency.py: 203 us against 198 us wall for one 20-step launch); graphs are for the one-kernel-per-step mode")
     ap.add_argument("--mt-window", type=int, default=0, help="MT19937-compat mode: precomputed outputs per episode window (0 = engine default)")
     ap.add_argument("--no-spin", action="store_true", help="skip the clock warm-up on a scratch env before the timed region")
     ap.add_argument("--spin-ms", type=float, default=6.0,
@@ -224,6 +228,7 @@ class Runner:
                 self.gen.manual_seed(2024 + env.cfg.lane_offset)
                 self.scale = torch.tensor([2.0, 3.0], device="cuda")
         self.graphs = {}
+        self.bound_calls = {}
         self.graph_kind = "hipGraph (torch.cuda.CUDAGraph)"
 
     def launch(self, n_steps):
@@ -276,6 +281,11 @@ class Runner:
             self.graphs[n_steps] = g
         return self.graphs[n_steps]
 
+    def bound(self, k):
+        if k not in self.bound_calls:
+            self.bound_calls[k] = self.env.bind_rollout(k, agent="sample" if self.agent == "uniform6" else "random", traj=self.traj)
+        return self.bound_calls[k]
+
     def launches(self, steps):
         """kernel launches of the dominant kernel the plan issues"""
         if self.mode != "rollout":
@@ -289,24 +299,42 @@ class Runner:
         """time exactly `steps` env steps; returns (wall seconds, event milliseconds)"""
         torch = self.torch
         plan = self.plan(steps)
+        direct = None
+        if use_graph and self.mode == "rollout" and not self.args.graph_rollout:
+            # K-step launches go straight through the C ABI, arguments marshalled beforehand (VecEWN.bind_rollout)
+            use_graph = False
+            direct = []
+            for g, reps in plan:
+                calls = [self.bound(min(self.K, g - d)) for d in range(0, g, self.K)]
+                direct += calls * reps
+            self.graph_kind = "direct C-ABI calls, arguments pre-marshalled (VecEWN.bind_rollout)"
         if use_graph:
             for g, _ in plan:
                 self.graph(g)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); e1.record()   # torch creates the hipEvent at an event's first record(): not inside the timed region (measured: 13-18 us against 4.5)
         if spin is not None:
             spin()      # capture / instantiate / upload left the GPU idle for milliseconds: bring its clocks back up (untimed, other state)
         barrier()
         t0 = time.perf_counter()
         e0.record()
-        for g, reps in plan:
-            for _ in range(reps):
-                if use_graph:
-                    self.graphs[g].replay()
-                else:
-                    self.launch(g)
+        ta = time.perf_counter()
+        if direct is not None:
+            for call in direct:
+                call()
+        else:
+            for g, reps in plan:
+                for _ in range(reps):
+                    if use_graph:
+                        self.graphs[g].replay()
+                    else:
+                        self.launch(g)
+        tb = time.perf_counter()
         e1.record()
+        tc = time.perf_counter()
         barrier()
         dt = time.perf_counter() - t0
+        self.host_us = {"e0.record": (ta - t0) * 1e6, "launches": (tb - ta) * 1e6, "e1.record": (tc - tb) * 1e6, "wait": (t0 + dt - tc) * 1e6}
         return dt, e0.elapsed_time(e1)
 
 
@@ -401,6 +429,8 @@ def main():
                 if (stable >= 3 and now - t_begin >= args.spin_ms * 1e-3) or now - t_begin >= 0.3:
                     break
     dt, ev_ms = runner.run(args.steps, barrier, use_graph=not args.no_graph, spin=spin)   # exactly K timed steps
+    if rank == 0:
+        print("host side of the timed region (us): " + ", ".join("%s %.1f" % kv for kv in runner.host_us.items()) + "; events %.1f" % (ev_ms * 1e3), file=sys.stderr)
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if (dist_on and args.backend == "nccl") else "cpu")
     ranks_seen = None
     if dist_on:
@@ -485,7 +515,7 @@ def main():
                 runner.K, ("per-step trajectory (obs, action, reward, flags) written to HBM, %s" %
                            ("one aligned %d-byte record per lane-step + f64 reward" % ((args.board_size ** 2 + 6 + 15) & ~15) if args.trajectory_layout == "record"
                             else "packed columns")) if runner.trajectory else "no trajectory output",
-                runner.graph_kind + " replay" if not args.no_graph else "eager")
+                (runner.graph_kind if runner.graph_kind.startswith("direct") else runner.graph_kind + " replay") if not args.no_graph else "eager")
         else:
             launch = "one ewn_step launch per env step; " + ("hipGraph replay (%s)" % ", ".join("%d x %d steps" % (r, g) for g, r in runner.plan(args.steps))
                                                              if not args.no_graph else "eager")

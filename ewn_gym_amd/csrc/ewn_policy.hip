@@ -34,10 +34,17 @@ int64_t ewn_policy_param_count(int board_size, int cube_layer)
     }
 }
 
-template <int S, int OPP, int NT>
+template <int S, int OPP, int NT, int TRJ = 0>
 static int pol_launch(const PolCfg &pc, const PolBuf &pb, hipStream_t s)
 {
-    auto kern = k_rollout_mlp<S, OPP, NT>;
+    if constexpr (TRJ == 0 && OPP == 0) {
+        // the trainer's call (FusedA2CTrainer): records from the initial observation on + the reward column, nothing else per step,
+        // sampled actions, no value output -- the instance that knows it at compile time
+        const bool trainer = pb.t_rec && pb.t_reward && pc.rec0 && !pc.want_value && !pc.deterministic && !pb.t_board && !pb.t_dice && !pb.t_action
+                             && !pb.t_term && !pb.t_trunc && !pb.t_info && !pb.t_logits && !pb.t_value && !pb.t_noise;
+        if (trainer) return pol_launch<S, OPP, NT, 1>(pc, pb, s);
+    }
+    auto kern = k_rollout_mlp<S, OPP, NT, TRJ>;
     const size_t lds = pol_lds_bytes<S, NT>(pc.want_value != 0);
     if (lds > 160 * 1024) return EWN_EUNSUPPORTED;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return EWN_ELAUNCH;

@@ -64,9 +64,14 @@ EWN_DEV float pol_uniform(u32 w0, int i)
 EWN_DEV float pol_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 
 // OPP 0: minimax max_depth 1-4 on a (level, count) table image; 1: RandomAgent.  Philox dice.
-template <int S, int OPP, int NT>
+// TRJ 1: the trainer's call, known at compile time -- records (row 0 = the initial observation) and the reward column, nothing else
+// written per step, actions sampled, no value output (FusedA2CTrainer; the gradient kernels recompute the forward pass).  0: everything
+// by PolCfg / PolBuf at run time (a dozen loop-invariant tests whose masks the compiler keeps in spilled SGPRs: 126 of them).
+template <int S, int OPP, int NT, int TRJ = 0>
 __global__ __launch_bounds__(NT, NT / 256) void k_rollout_mlp(PolCfg c, PolBuf B)
 {
+    constexpr bool FIX = TRJ == 1;
+    const bool want_value = !FIX && c.want_value, deterministic = !FIX && c.deterministic, rec0 = FIX || c.rec0;
     constexpr int T = 2, GPB = NT / T, NW = NT / 64, CELLS = S * S, STR = RecGeo<S>::STR, NCH = RecGeo<S>::NCH;
     using G = MlpGeo<S>;
     extern __shared__ __attribute__((aligned(16))) int8_t lds[];
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(NT, NT / 256) void k_rollout_mlp(PolCfg c, PolBuf B
     int8_t *tb = lds;
     int8_t *Wpi = lds + FAST_TAB_BYTES(S);
     int8_t *Wvf = Wpi + Q3::FWD_BYTES;
-    float *lx_all = (float *)(Wpi + (c.want_value ? 2 : 1) * Q3::FWD_BYTES);
+    float *lx_all = (float *)(Wpi + (want_value ? 2 : 1) * Q3::FWD_BYTES);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float *LX = lx_all + wave * 32 * 8;                    // this wave's 8 floats per game of head outputs
     int8_t *slots = (int8_t *)(lx_all + GPB * 8);
@@ -83,7 +88,7 @@ __global__ __launch_bounds__(NT, NT / 256) void k_rollout_mlp(PolCfg c, PolBuf B
     tables_to_lds_nt<FAST_TAB_BYTES(S), NT>(tb, (const int8_t *)B.tables);
     const FastTab<S> *Tb = (const FastTab<S> *)tb;
     mlp3_pack_fwd<S>(Wpi, B.params, 0, threadIdx.x, NT);
-    if (c.want_value) mlp3_pack_fwd<S>(Wvf, B.params, 1, threadIdx.x, NT);
+    if (want_value) mlp3_pack_fwd<S>(Wvf, B.params, 1, threadIdx.x, NT);
 
     const int g0 = (int)blockIdx.x * GPB, ng = min(GPB, c.N - g0);
     const int gl = threadIdx.x / T, sub = threadIdx.x % T, game = g0 + gl;
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(NT, NT / 256) void k_rollout_mlp(PolCfg c, PolBuf B
     __syncthreads();                                       // every game is in registers: the board area becomes the per-game slots
     int8_t *slot = slots + gl * STR;
     rec_slot_build<S, T>(Tb, s, sub, slot);
-    if (B.t_rec && c.rec0 && live) rec_store<S, T>(slot, sub, dice, 0, 0, 0, 0, 0, B.t_rec + (size_t)game * STR);
+    if ((FIX || B.t_rec) && rec0 && live) rec_store<S, T>(slot, sub, dice, 0, 0, 0, 0, 0, B.t_rec + (size_t)game * STR);
     double ret_acc = 0.0;
     int n_steps = 0, n_eps = 0, n_wins = 0;
     // The two waves that share a SIMD run the same loop; started together they stay in phase -- both in the network (the matrix
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(NT, NT / 256) void k_rollout_mlp(PolCfg c, PolBuf B
             float lo[MLP_NA];
             mlp3_forward<S, MLP_NA>(Wpi, lane, xb, h1, h2, lo);
             if (lane < 32) { *(float4 *)(LX + lane * 8) = make_float4(lo[0], lo[1], lo[2], lo[3]); LX[lane * 8 + 4] = lo[4]; }
-            if (c.want_value) {
+            if (want_value) {
                 float vo[1];
                 mlp3_forward<S, 1>(Wvf, lane, xb, h1, h2, vo);
                 if (lane < 32) LX[lane * 8 + 5] = vo[0];
@@ -159,11 +164,11 @@ __global__ __launch_bounds__(NT, NT / 256) void k_rollout_mlp(PolCfg c, PolBuf B
         const u32 w0 = agent_hash(r.seed_mix() ^ ((u32)tol * 0x632BE5ABu), r.draws(), (u32)(c.lane_offset + game), c.key ^ c.noise_key);
         float u[5], gn[5];
         #pragma unroll
-        for (int i = 0; i < 5; i++) { u[i] = pol_uniform(w0, i); gn[i] = c.deterministic ? 0.0f : -pol_log(-pol_log(u[i])); }
+        for (int i = 0; i < 5; i++) { u[i] = pol_uniform(w0, i); gn[i] = deterministic ? 0.0f : -pol_log(-pol_log(u[i])); }
         const float z0 = lg.x + gn[0], z1 = lg.y + gn[1], z2 = lg.z + gn[2], z3 = lg.w + gn[3], z4 = lg4 + gn[4];
         const int aflag = z1 > z0 ? 1 : 0;
         const int adir = z3 > z2 ? (z4 > z3 ? 2 : 1) : (z4 > z2 ? 2 : 0);
-        if (writer) {
+        if (!FIX && writer) {
             const size_t o = (size_t)kstep * c.N + game;
             if (B.t_logits) { float *p = B.t_logits + o * 5; p[0] = lg.x; p[1] = lg.y; p[2] = lg.z; p[3] = lg.w; p[4] = lg4; }
             if (B.t_value) B.t_value[o] = val;
@@ -226,7 +231,9 @@ __global__ __launch_bounds__(NT, NT / 256) void k_rollout_mlp(PolCfg c, PolBuf B
         __builtin_amdgcn_wave_barrier();
         if (live) {
             const size_t o = (size_t)kstep * c.N + game;
-            if (sub == 0) {
+            if constexpr (FIX) {
+                if (sub == 0) B.t_reward[o] = reward;
+            } else if (sub == 0) {
                 if (B.t_action) ((uint16_t *)B.t_action)[o] = (uint16_t)((uint8_t)aflag | ((uint16_t)(uint8_t)adir << 8));
                 if (B.t_dice) B.t_dice[o] = (int8_t)dice;
                 if (B.t_reward) B.t_reward[o] = reward;
@@ -234,8 +241,8 @@ __global__ __launch_bounds__(NT, NT / 256) void k_rollout_mlp(PolCfg c, PolBuf B
                 if (B.t_trunc) B.t_trunc[o] = (uint8_t)trunc;
                 if (B.t_info) B.t_info[o] = (uint8_t)info;
             }
-            if (B.t_rec) rec_store<S, T>(slot, sub, dice, aflag, adir, term, trunc, info, B.t_rec + (o + (c.rec0 ? (size_t)c.N : 0)) * STR);
-            if (B.t_board && sub == 0) { int8_t *dst = B.t_board + o * CELLS; for (int i = 0; i < CELLS; i++) dst[i] = slot[i]; }
+            if (FIX || B.t_rec) rec_store<S, T>(slot, sub, dice, aflag, adir, term, trunc, info, B.t_rec + (o + (rec0 ? (size_t)c.N : 0)) * STR);
+            if (!FIX && B.t_board && sub == 0) { int8_t *dst = B.t_board + o * CELLS; for (int i = 0; i < CELLS; i++) dst[i] = slot[i]; }
         }
     }
     // ---- the state goes back to HBM once, through the packed board area

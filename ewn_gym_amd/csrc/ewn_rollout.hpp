@@ -444,6 +444,11 @@ __global__ __launch_bounds__(D3_BS, (OPP == 2 ? 2 : 1)) void k_rollout_slots(Rol
     double reward = 0.0, best = 0.0;
     int term = 0, trunc = 0, info = EWN_INFO_NONE, aflag = 0, adir = 0, oflag = 0, odir = 0;
     bool reply = false;
+#ifdef EWN_ROLLOUT_STAMPS
+    unsigned long long st_acc[6] = { 0, 0, 0, 0, 0, 0 }, st_prev;   // [4] counts the iterations
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev) :: "memory");
+    const unsigned long long st_begin = st_prev;
+#endif
     while (true) {
         const bool pending = live && kdone < c.K;
         if (__builtin_amdgcn_ballot_w64(pending) == 0) break; // this wave's games have all played K steps
@@ -459,11 +464,13 @@ __global__ __launch_bounds__(D3_BS, (OPP == 2 ? 2 : 1)) void k_rollout_slots(Rol
                 reply = roll_agent_half<S>(Tb, s, aflag, adir, dice, r, c.reward, reward, term, trunc, info, slot_m);
             }
         }
+        RSTAMP(0); // start of an env step: the agent's action, RNG block, agent half
         // one cube's three roots of the opponent's search, run by every lane (lanes without a pending reply compute on a harmless
         // state, so the DPP exchanges inside always see their partners)
         bool second = false;
         if constexpr (OPP == 0) best = d3_search<S, T, H2, true>(Tb, s, dice, sub, c.depth, oflag, odir, phase, best, &second);
         else best = d5c_search<S, TS, true>(Tb, s, dice, T > 2 ? (sub & 1) : sub, oflag, odir, phase, best, &second);
+        RSTAMP(1); // search
         if (pending && phase == 0 && reply && second) phase = 1; // the same env step goes on with the second cube
         else if (pending) {
             phase = 0;
@@ -480,6 +487,7 @@ __global__ __launch_bounds__(D3_BS, (OPP == 2 ? 2 : 1)) void k_rollout_slots(Rol
                 }
             }
             // ---- row kdone of the trajectory
+            RSTAMP(2); // opponent half + bookkeeping + auto-reset (stamps inside a divergent region: the wave's time while any lane is here)
             const size_t o = (size_t)kdone * c.N + game;
             if constexpr (TRJ == 1) {
                 if (sub == 0) B.t_reward[o] = reward;
@@ -513,14 +521,27 @@ __global__ __launch_bounds__(D3_BS, (OPP == 2 ? 2 : 1)) void k_rollout_slots(Rol
             }
             kdone++;
         }
+        RSTAMP(3); // trajectory row
+#ifdef EWN_ROLLOUT_STAMPS
+        st_acc[4]++;
+#endif
     }
+#ifdef EWN_ROLLOUT_STAMPS
+    if (B.ret_sum && (threadIdx.x & 63) == 0) {
+        unsigned long long *o = (unsigned long long *)B.ret_sum + (size_t)(blockIdx.x * (D3_BS / 64) + (threadIdx.x >> 6)) * 8;
+        for (int i = 0; i < 6; i++) o[i] = st_acc[i];
+        o[6] = st_begin; o[7] = st_prev;
+    }
+#endif
     // ---- the state goes back to HBM once, through the packed board area
     __syncthreads();
     if (live) d3_encode<S, T>(Tb, s, sub, lds + gl * CELLS);
     if (writer) {
         if (!frozen0) { *rng_hdr_ptr(B.rng, game) = r.header(); B.dice[game] = (int8_t)dice; }
         B.done[game] = frozen ? 1 : 0;
+#ifndef EWN_ROLLOUT_STAMPS
         if (B.ret_sum) B.ret_sum[game] += ret_acc;
+#endif
         if (B.n_steps) B.n_steps[game] += n_steps;
         if (B.n_episodes) B.n_episodes[game] += n_eps;
         if (B.n_wins) B.n_wins[game] += n_wins;

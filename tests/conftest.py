@@ -58,6 +58,7 @@ def pytest_sessionstart(session):
         PRELAUNCH["bench_2ranks_step"] = _run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--lanes", "8192", "--mode", "step"] + common)
         PRELAUNCH["bench_1rank_step"] = _run([sys.executable, "bench.py", "--gpus", "1", "--lanes", "16384", "--mode", "step"] + common)
         PRELAUNCH["bench_short"] = _run([sys.executable, "bench.py", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-extras"])
+        PRELAUNCH["bench_short_graph"] = _run([sys.executable, "bench.py", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-extras", "--graph-rollout"])
         # the RCCL branch at world_size 1: bench.py's N>1 code path under backend nccl, and the trainers' gradient all-reduce
         PRELAUNCH["bench_nccl_w1"] = _run([sys.executable, "bench.py", "--gpus", "1", "--force-collectives", "--backend", "nccl", "--lanes", "16384"] + common)
         PRELAUNCH["nccl_selftest"] = _run([sys.executable, "tools/nccl_selftest.py"])

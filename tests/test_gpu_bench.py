@@ -33,12 +33,15 @@ def test_bench_gpus2_starts_two_ranks_and_shards_are_invariant(prelaunched, suff
 
 
 def test_short_bench_line_is_self_consistent(prelaunched):
-    """the driver's own invocation shape (--steps 20): graphs of exactly the timed steps, event time inside wall time"""
+    """the driver's own invocation shape (--steps 20): ONE 20-step launch in the timed region (a direct C-ABI call; --graph-rollout
+    replays it as a hipGraph and must leave the same state), event time inside wall time"""
     b = _line(prelaunched, "bench_short")
+    g = _line(prelaunched, "bench_short_graph")
+    assert "direct C-ABI" in b["config"]["launch"] and "hipGraph" in g["config"]["launch"] and "replay" in g["config"]["launch"]
+    assert b["state_digest"] == g["state_digest"] and b["config"]["kernel_launches_in_timed_region"] == g["config"]["kernel_launches_in_timed_region"] == 1
     assert b["steps"] == 20 and b["metric"].startswith("env steps/sec") and b["unit"] == "env steps/sec"
     r = b["roofline"]
     assert r["kernel_ms"] * b["config"]["kernel_launches_in_timed_region"] <= b["ms_per_step"] * b["steps"] * 1.0001
-    assert "hipGraph" in b["config"]["launch"] and "replay" in b["config"]["launch"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
     if r["valu_issue"]:
         assert 0 < r["valu_issue"]["frac"] <= 1.0

@@ -43,3 +43,29 @@ for rep in range(12):
 for k, v in res.items():
     v = sorted(v)
     print("%-9s median %.1f us  min %.1f  max %.1f" % (k, v[len(v) // 2], v[0], v[-1]))
+
+# host-side breakdown of the direct-call region: fresh events (torch creates the hipEvent at the first record) against re-used ones
+for fresh in (True, False, False):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if not fresh:
+        e0.record(); e1.record()
+    torch.cuda.synchronize()
+    t = [time.perf_counter()]
+    e0.record(); t.append(time.perf_counter())
+    bound(); t.append(time.perf_counter())
+    e1.record(); t.append(time.perf_counter())
+    torch.cuda.synchronize(); t.append(time.perf_counter())
+    print("fresh events %-5s: e0.record %.1f us, call %.1f, e1.record %.1f, synchronize %.1f, total %.1f; event time %.1f us"
+          % (fresh, *[(b - a) * 1e6 for a, b in zip(t, t[1:])], (t[-1] - t[0]) * 1e6, e0.elapsed_time(e1) * 1e3))
+# the same region with the wait done by polling the second event from the host
+for _ in range(3):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); e1.record(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record(); bound(); e1.record()
+    while not e1.query():
+        pass
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    print("re-used events, host polls e1: %.1f us until the event is seen, %.1f with the synchronize after it; event time %.1f us"
+          % ((t1 - t0) * 1e6, (time.perf_counter() - t0) * 1e6, e0.elapsed_time(e1) * 1e3))
