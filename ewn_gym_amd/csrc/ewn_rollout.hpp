@@ -204,7 +204,8 @@ EWN_DEV void roll_opponent_half(const FastTab<S> *Tb, RState<S> &s, u32 e, int o
 // max_depth 1-4 ('hybrid'); 2: of max_depth 5-6.  OPP as in k_step_d3: 0 minimax max_depth 1-4, 1 RandomAgent, 2 minimax 5-6.
 // H2: the opponent's search runs on the 'two_min_dist' table image (envs/minimax_ewn.py:133-178; a side's index is the sum of its two
 // smallest distances, ewn_fast.hpp): RandomAgent / sample agents only
-template <int S, int T, int OPP, int RNGK, int AGENT, bool H2 = false>
+// TRJ 1: the trajectory is the record + the reward column and nothing else, known at compile time (see k_rollout_slots below)
+template <int S, int T, int OPP, int RNGK, int AGENT, bool H2 = false, int TRJ = 0>
 __global__ __launch_bounds__(D3_BS, ((OPP == 2 || AGENT == 2) ? 2 : 1)) void k_rollout_d3(RollCfg c, RollBuf B) // the max_depth 5 / 6 search: hold it to 256 registers (two waves per SIMD)
 {
     constexpr int CELLS = S * S, GPB = D3_BS / T; // games per block
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(D3_BS, ((OPP == 2 || AGENT == 2) ? 2 : 1)) void k_r
     int8_t *mine = lds + gl * CELLS;
     RState<S> s;
     d3_decode<S, T>(live ? mine : lds, sub, garr + gl * 16, s);
-    const bool want_board = B.t_board != nullptr;
+    const bool want_board = TRJ == 0 && B.t_board != nullptr;
     double ret_acc = 0.0;
     int n_steps = 0, n_eps = 0, n_wins = 0;
 
@@ -314,7 +315,9 @@ __global__ __launch_bounds__(D3_BS, ((OPP == 2 || AGENT == 2) ? 2 : 1)) void k_r
         }
         RSTAMP(3); // opponent half + bookkeeping + auto-reset
         // ---- this step's row of the trajectory
-        if (writer) {
+        if constexpr (TRJ == 1) {
+            if (writer) B.t_reward[(size_t)kstep * c.N + game] = reward;
+        } else if (writer) {
             const size_t o = (size_t)kstep * c.N + game;
             if (B.t_action) ((uint16_t *)B.t_action)[o] = (uint16_t)((uint8_t)aflag | ((uint16_t)(uint8_t)adir << 8));
             if (B.t_dice) B.t_dice[o] = (int8_t)dice;
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(D3_BS, ((OPP == 2 || AGENT == 2) ? 2 : 1)) void k_r
             if (B.t_trunc) B.t_trunc[o] = (uint8_t)trunc;
             if (B.t_info) B.t_info[o] = (uint8_t)info;
         }
-        if (B.t_rec) { // one aligned record per lane-step (ewn_rollout_out.record), the board re-encoded into the game's slot
+        if (TRJ == 1 || B.t_rec) { // one aligned record per lane-step (ewn_rollout_out.record), the board re-encoded into the game's slot
             rec_slot_build<S, T>(Tb, s, sub, rec_slot);
             if (live) rec_store<S, T>(rec_slot, sub, dice, aflag, adir, term, trunc, info, B.t_rec + ((size_t)kstep * c.N + game) * RecGeo<S>::STR);
             __builtin_amdgcn_wave_barrier();
