@@ -146,7 +146,7 @@ def main():
         mix = json.load(open(mixp))
         # the peak the dominant (rollout) kernel's instruction mix could issue at, chip-wide
         for kname, kv in mix["kernels"].items():
-            if "k_rollout_slotsILi5ELi2ELi0ELi1ELb0E" in kname and "peak_wave_insts_per_s" in kv:  # the headline instance
+            if "k_rollout_slotsILi5ELi2ELi0ELi1ELb0ELi1E" in kname and "peak_wave_insts_per_s" in kv:  # the headline instance (record-only trajectory)
                 out["valu_issue_peak_per_s"] = kv["peak_wave_insts_per_s"]["hot_loop"]
                 out["valu_issue_peak_source"] = "tools/isa_mix.py hot loop of %s priced with tools/valu_probe.py (valu_probe.json beside it)" % kname
     json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
