@@ -698,6 +698,104 @@ EWN_DEV PState pstate_from_gstate(const Geom &g, const GState<1> &c)
     return st;
 }
 
+// ---------------------------------------------------------------- ewn_step_k for the geometries without a table image
+//
+// cube_layer 4 / 5 (ten / fifteen cubes a side) and boards of 9x9 .. 11x11: the generic rules and the compile-time-unrolled recursion
+// of k_step<NW, 0, 0>, one thread per game, K env steps per launch with the state in registers -- what k_rollout_d3 is for the
+// table-driven geometries (eval_minimax.py:16-50's predict / step loop with RandomAgent or env.action_space.sample() as the agent,
+// RandomAgent or minimax opponents of the four evaluate() heuristics).  Same trajectory, same totals, same results as K ewn_step calls.
+struct GenRoll { int K, agent_sample, strd; };   // strd: bytes per game of the LDS staging area (a record, or S*S)
+
+template <int NW>
+__global__ __launch_bounds__(BS) void k_rollout_generic(Geom g, KCfg c, KState st, GenRoll gr, RollBuf B)
+{
+    extern __shared__ __attribute__((aligned(16))) int8_t lds[];   // [BS][strd]: packed boards in and out, trajectory rows in between
+    const int tid = (int)threadIdx.x, lane0 = (int)blockIdx.x * BS, nl = min(BS, c.N - lane0), lane = lane0 + tid;
+    const bool live = lane < c.N;
+    uint4 hdr = make_uint4(0u, 0u, 0u, 0u);
+    int dice = 1;
+    bool frozen = true;
+    if (live) { hdr = *rng_hdr_ptr(st.rng, lane); dice = st.dice[lane]; frozen = st.done[lane] != 0; }
+    const bool frozen0 = frozen;
+    block_copy_in(lds, st.board + (size_t)lane0 * g.cells, nl * g.cells);
+    __syncthreads();
+    GState<NW> s;
+    decode_board<NW>(g, lds + (live ? tid : 0) * g.cells, s);
+    __syncthreads();
+    LaneRng r; r.load(c.rng_kind, hdr, rng_win_ptr(st.rng, c.N, c.W, live ? lane : 0, RNGF_CUR(hdr.w)), c.W, c.key);
+    r.begin_kernel();
+    double ret_acc = 0.0;
+    int n_steps = 0, n_eps = 0, n_wins = 0;
+
+    for (int kstep = 0; kstep < gr.K; kstep++) {
+        const bool active = live && !frozen;
+        StepRes o; o.reward = 0.0; o.term = (live && frozen) ? 1 : 0; o.trunc = 0; o.info = EWN_INFO_NONE;
+        int aflag = 0, adir = 0;
+        if (active) {
+            // the stand-in agent: RandomAgent.predict (the hash pick of ewn_step_out.random_action) or action_space.sample()
+            const u32 w = agent_hash(r.seed_mix(), r.draws(), (u32)(c.lane_offset + lane), c.key);
+            if (gr.agent_sample) { const int a6 = (int)__umulhi(w, 6u); aflag = a6 >= 3 ? 1 : 0; adir = a6 - 3 * aflag; }
+            else {
+                const int n = for_each_legal<0, NW>(g, s, dice, [](int, int, int) { return true; });
+                if (n > 0) {
+                    const int pick = (int)__umulhi(w, (u32)n);
+                    int i = 0;
+                    for_each_legal<0, NW>(g, s, dice, [&](int flag, int, int dir) { if (i == pick) { aflag = flag; adir = dir; } i++; return i <= pick; });
+                }
+            }
+            r.prefetch();
+            r.begin_step();
+            if (step_agent<NW>(g, c, s, dice, aflag, adir, r, nullptr, o)) {            // envs/ewn.py:438-458
+                int oflag = 0, odir = 0;
+                if (c.opp == EWN_OPP_RANDOM) policy_random<NW>(g, s, dice, r, oflag, odir);
+                else policy_minimax_rt<NW>(g, s, dice, c.depth, c.heur, oflag, odir);
+                step_opponent<NW>(g, c, s, dice, oflag, odir, r, nullptr, o);              // envs/ewn.py:464-486
+            }
+            ret_acc += o.reward; n_steps++; n_eps += o.term; n_wins += o.info == EWN_INFO_WON ? 1 : 0;
+            if (o.term) { if (c.autoreset) lane_auto_reset<NW>(g, c, st.rng, lane, s, dice, r); else frozen = true; }
+        }
+        // ---- this step's trajectory row
+        if (live) {
+            const size_t oo = (size_t)kstep * c.N + lane;
+            if (B.t_action) ((uint16_t *)B.t_action)[oo] = (uint16_t)((uint8_t)aflag | ((uint16_t)(uint8_t)adir << 8));
+            if (B.t_dice) B.t_dice[oo] = (int8_t)dice;
+            if (B.t_reward) B.t_reward[oo] = o.reward;
+            if (B.t_term) B.t_term[oo] = (uint8_t)o.term;
+            if (B.t_trunc) B.t_trunc[oo] = (uint8_t)o.trunc;
+            if (B.t_info) B.t_info[oo] = (uint8_t)o.info;
+        }
+        if (B.t_board) {
+            if (live) encode_board<NW>(g, s, lds + tid * g.cells);
+            __syncthreads();
+            block_copy_out(B.t_board + ((size_t)kstep * c.N + lane0) * g.cells, lds, nl * g.cells);
+            __syncthreads();
+        }
+        if (B.t_rec) { // one aligned record per lane-step: board | dice | action | flags | padding (ewn_rollout_out.record)
+            if (live) {
+                int8_t *rec = lds + tid * gr.strd;
+                for (int i = g.cells; i < gr.strd; i++) rec[i] = 0;
+                encode_board<NW>(g, s, rec);
+                rec[g.cells] = (int8_t)dice; rec[g.cells + 1] = (int8_t)aflag; rec[g.cells + 2] = (int8_t)adir;
+                rec[g.cells + 3] = (int8_t)o.term; rec[g.cells + 4] = (int8_t)o.trunc; rec[g.cells + 5] = (int8_t)o.info;
+            }
+            __syncthreads();
+            block_copy_out((int8_t *)B.t_rec + ((size_t)kstep * c.N + lane0) * gr.strd, lds, nl * gr.strd);
+            __syncthreads();
+        }
+    }
+    if (live) {
+        encode_board<NW>(g, s, lds + tid * g.cells);
+        if (!frozen0) { *rng_hdr_ptr(st.rng, lane) = r.header(); st.dice[lane] = (int8_t)dice; }
+        st.done[lane] = frozen ? 1 : 0;
+        if (B.ret_sum) B.ret_sum[lane] += ret_acc;
+        if (B.n_steps) B.n_steps[lane] += n_steps;
+        if (B.n_episodes) B.n_episodes[lane] += n_eps;
+        if (B.n_wins) B.n_wins[lane] += n_wins;
+    }
+    __syncthreads();
+    block_copy_out(st.board + (size_t)lane0 * g.cells, lds, nl * g.cells);
+}
+
 struct MctsRoll { int K, total, gl, agent_sample, strd, gpb; };   // strd: bytes per game of the dynamic LDS area (a record, or S*S)
 
 // mr.gpb games per block of BS threads: the rules run one thread per game (the block's first lanes), the playouts on all BS lanes.
@@ -1131,6 +1229,18 @@ static int rollout_plan(const ewn_config *cfg, const Geom &g, const KCfg &k, int
     return EWN_OK;
 }
 
+// geometries without a table image (cube_layer 4 / 5, boards of 9x9 .. 11x11) and RandomAgent / the four evaluate() heuristics as the
+// opponent: the generic K-step kernel (k_rollout_generic); un-shaped, RandomAgent / sample agents, MT19937-compat dice only without auto-reset
+static int generic_rollout_plan(const ewn_config *cfg, const Geom &g, int agent_kind)
+{
+    if (fast_tables_bytes(g.S, g.L) > 0 || cfg->shaped) return EWN_EUNSUPPORTED;
+    if (cfg->opponent_kind == EWN_OPP_MINIMAX) { if (cfg->heuristic == EWN_H_SIM_WINRATE) return EWN_EUNSUPPORTED; }
+    else if (cfg->opponent_kind != EWN_OPP_RANDOM) return EWN_EUNSUPPORTED;
+    if (agent_kind != EWN_AGENT_RANDOM && agent_kind != EWN_AGENT_SAMPLE) return agent_kind == EWN_AGENT_MINIMAX ? EWN_EUNSUPPORTED : EWN_EINVAL;
+    if (cfg->rng_kind == EWN_RNG_MT19937 && cfg->autoreset) return EWN_EUNSUPPORTED;
+    return EWN_OK;
+}
+
 // the flat Monte-Carlo opponent inside ewn_step_k (k_rollout_mcts): byte-per-cube playouts (cube_layer <= 3, boards <= 8x8), un-shaped,
 // RandomAgent / sample agents; MT19937-compat dice only without auto-reset (as every K-step kernel)
 static int mcts_rollout_plan(const ewn_config *cfg, const Geom &g, int agent_kind)
@@ -1168,6 +1278,7 @@ int ewn_step_k_supported(const ewn_config *cfg, int agent_kind, int agent_max_de
     if (rc) return rc;
     if (agent_kind == EWN_AGENT_MLP) { rc = ewn_policy_supported(cfg, g); return rc == EWN_OK ? 1 : (rc == EWN_EUNSUPPORTED ? 0 : rc); } // ewn_step_k_policy
     if (cfg->opponent_kind == EWN_OPP_MCTS) { rc = mcts_rollout_plan(cfg, g, agent_kind); return rc == EWN_OK ? 1 : (rc == EWN_EUNSUPPORTED ? 0 : rc); }
+    if (generic_rollout_plan(cfg, g, agent_kind) == EWN_OK) return 1;
     int T, opp, agent;
     rc = rollout_plan(cfg, g, k, agent_kind, agent_max_depth, T, opp, agent);
     return rc == EWN_OK ? 1 : (rc == EWN_EUNSUPPORTED ? 0 : rc);
@@ -1200,6 +1311,22 @@ int ewn_step_k(const ewn_config *cfg, const ewn_state *st, int K, int agent_kind
         if (gpb_env) gpb = gpb_env;
         MctsRoll mr = { K, k.nsim_total, playout_group_log2(k.nsim_total), agent_kind == EWN_AGENT_SAMPLE ? 1 : 0, (g.cells + 6 + 15) & ~15, gpb };
         k_rollout_mcts<<<dim3((unsigned)((k.N + mr.gpb - 1) / mr.gpb)), BS, (size_t)mr.gpb * mr.strd, (hipStream_t)stream>>>(g, k, kstate(st), mr, rb);
+        return launch_status();
+    }
+    if (generic_rollout_plan(cfg, g, agent_kind) == EWN_OK) {
+        if (!st || !st->board || !st->dice || !st->done || !st->rng) return EWN_ENULL;
+        RollBuf rb;
+        memset(&rb, 0, sizeof(rb));
+        if (out) {
+            rb.t_board = out->board; rb.t_dice = out->dice; rb.t_action = out->action; rb.t_reward = out->reward;
+            rb.t_term = out->terminated; rb.t_trunc = out->truncated; rb.t_info = out->info; rb.t_rec = out->record;
+            rb.ret_sum = out->return_sum; rb.n_steps = out->n_steps; rb.n_episodes = out->n_episodes; rb.n_wins = out->n_wins;
+        }
+        GenRoll gr = { K, agent_kind == EWN_AGENT_SAMPLE ? 1 : 0, (g.cells + 6 + 15) & ~15 };
+        const KState ks = kstate(st);
+        const size_t lds = (size_t)BS * gr.strd;
+        hipStream_t s = (hipStream_t)stream;
+        BY_NW(g, (k_rollout_generic<NWV><<<GRID(k.N), BS, lds, s>>>(g, k, ks, gr, rb)));
         return launch_status();
     }
     if (!st || !st->board || !st->dice || !st->done || !st->rng || !st->tables) return EWN_ENULL;

@@ -152,8 +152,10 @@ class VecEWN:
     # -- K env steps per launch with an in-engine agent (ewn_step_k; eval_minimax.py:16-50's loop on the device)
     def supports_rollout(self, agent="random", agent_max_depth=3):
         """True when ewn_step_k exists for this configuration and agent"""
-        if self.tables is None or agent not in AGENT:
+        if agent not in AGENT:
             return False
+        if self.tables is None and int(self.lib.ewn_tables_bytes(self.S, self.L)) > 0:
+            return False           # use_tables=False on a table geometry (geometries WITHOUT a table image run the generic K-step kernel)
         return self.lib.ewn_step_k_supported(C.byref(self.cfg), AGENT[agent], int(agent_max_depth)) == 1
 
     def alloc_rollout(self, K, board=True, layout="columns", initial_obs=False):

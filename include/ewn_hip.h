@@ -220,7 +220,9 @@ typedef struct ewn_rollout_out {
  * EWN_ROLLOUT_T are set in the environment; tests pin the defaults. */
 int ewn_lanes_per_game(const ewn_config *cfg, int entry);
 
-/* 1 if ewn_step_k serves this configuration and agent, 0 if not, < 0 on an invalid configuration */
+/* 1 if ewn_step_k serves this configuration and agent, 0 if not, < 0 on an invalid configuration.  Geometries without a table
+ * image (cube_layer 4 / 5, boards of 9x9 .. 11x11) are served by the generic one-thread-per-game K-step kernel for the RandomAgent /
+ * sample agents against RandomAgent or minimax opponents of the four evaluate() heuristics (no ewn_state.tables needed). */
 int ewn_step_k_supported(const ewn_config *cfg, int agent_kind, int agent_max_depth);
 /* K >= 1 steps of every lane; out may be NULL (only the state advances).  No scratch; one kernel launch. */
 int ewn_step_k(const ewn_config *cfg, const ewn_state *st, int K, int agent_kind, int agent_max_depth,

@@ -224,6 +224,23 @@ def test_rollout_slot_task_kernel_frozen_lanes_and_numpy_dice(ea):
     _rollout_vs_oracle(ea, 140000, 0, 200, 6, 2, opponent_policy="minimax", max_depth=5, rng="philox", philox_key=5, board_column=False)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(board_size=7, cube_layer=4, opponent_policy="minimax", max_depth=3), dict(board_size=7, cube_layer=5, opponent_policy="minimax", max_depth=2, heuristic="two_min_dist"),
+    dict(board_size=9, cube_layer=3, opponent_policy="minimax", max_depth=3), dict(board_size=11, cube_layer=3, opponent_policy="random"),
+    dict(board_size=6, cube_layer=4, opponent_policy="random"), dict(board_size=7, cube_layer=4, opponent_policy="minimax", max_depth=1, heuristic="attk", agent="sample"),
+], ids=lambda kw: "-".join("%s=%s" % kv for kv in sorted(kw.items())))
+def test_rollout_geometries_without_a_table_image(ea, kw):
+    """cube_layer 4 / 5 and boards of 9x9 .. 11x11 have no table image: ewn_step_k plays them on the generic K-step kernel
+    (one thread per game, the rules and the recursion of the generic step kernel) -- every column, both layouts, the carried-over
+    state and the totals against the oracle; auto-reset, frozen lanes with numpy-compatible dice"""
+    kw = dict(kw)
+    agent = kw.pop("agent", "random")
+    N = 2500
+    _rollout_vs_oracle(ea, N, 1200, 1500, 7, 3, agent=agent, rng="philox", philox_key=77, **kw)
+    _rollout_vs_oracle(ea, N, 0, 300, 7, 2, agent=agent, layout="record", rng="philox", philox_key=78, **kw)
+    _rollout_vs_oracle(ea, N, 2200, 2500, 9, 3, agent=agent, autoreset=False, rng="mt19937", **kw)
+
+
 def test_bound_rollout_call_is_the_same_launch(ea):
     """VecEWN.bind_rollout: the pre-marshalled call leaves the same state and trajectory as rollout()"""
     outs = []
