@@ -398,7 +398,8 @@ __global__ __launch_bounds__(D3_BS, ((OPP == 2 || AGENT == 2) ? 2 : 1)) void k_r
 // for p = the share of two-cube decisions, against K iterations of twice the search length.
 // TRJ: what the trajectory is, known at compile time or not.  0: whatever RollBuf's pointers say (every column optional: a dozen
 // loop-invariant null tests, which the compiler keeps as 64-bit masks in SGPRs, spills to VGPR lanes and reads back with ~70
-// v_readlane per iteration); 1: the record layout with its reward column and nothing else (what bench.py and the trainers ask for).
+// v_readlane per iteration); 1: the record layout with its reward column and nothing else (what bench.py and the trainers ask for);
+// 2: no trajectory at all, only the final state and the per-lane totals (tournaments).
 template <int S, int T, int OPP, int RNGK, bool H2 = false, int TRJ = 0>
 __global__ __launch_bounds__(D3_BS, (OPP == 2 ? 2 : 1)) void k_rollout_slots(RollCfg c, RollBuf B)
 {
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(D3_BS, (OPP == 2 ? 2 : 1)) void k_rollout_slots(Rol
     d3_decode<S, T>(live ? lds + gl * CELLS : lds, sub, garr + gl * 16, s);
     __syncthreads();                                // every game is in registers: the board area becomes the per-game slots
     int8_t *slot_b = lds + gl * STR;
-    const bool want_slot = TRJ == 1 || B.t_board != nullptr || B.t_rec != nullptr;
+    const bool want_slot = TRJ == 1 || (TRJ == 0 && (B.t_board != nullptr || B.t_rec != nullptr));
     int8_t *slot_m = want_slot ? slot_b : nullptr;  // kept current by the two halves of a step and by the auto-reset
     if (want_slot) rec_slot_build<S, T>(Tb, s, sub, slot_b);
     double ret_acc = 0.0;
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(D3_BS, (OPP == 2 ? 2 : 1)) void k_rollout_slots(Rol
             const size_t o = (size_t)kdone * c.N + game;
             if constexpr (TRJ == 1) {
                 if (sub == 0) B.t_reward[o] = reward;
-            } else if (sub == 0) {
+            } else if (TRJ == 0 && sub == 0) {
                 if (B.t_action) ((uint16_t *)B.t_action)[o] = (uint16_t)((uint8_t)aflag | ((uint16_t)(uint8_t)adir << 8));
                 if (B.t_dice) B.t_dice[o] = (int8_t)dice;
                 if (B.t_reward) B.t_reward[o] = reward;
@@ -503,7 +504,7 @@ __global__ __launch_bounds__(D3_BS, (OPP == 2 ? 2 : 1)) void k_rollout_slots(Rol
                 if (B.t_info) B.t_info[o] = (uint8_t)info;
             }
             if (want_slot) __builtin_amdgcn_wave_barrier(); // this step's byte stores of every lane of the game are issued before its slot is read
-            if (TRJ == 1 || B.t_rec) rec_store<S, T>(slot_b, sub, dice, aflag, adir, term, trunc, info, B.t_rec + o * STR);
+            if (TRJ == 1 || (TRJ == 0 && B.t_rec)) rec_store<S, T>(slot_b, sub, dice, aflag, adir, term, trunc, info, B.t_rec + o * STR);
             if (TRJ == 0 && B.t_board) {
                 // the game's board out of its LDS slot (LDS operations of one wave execute in program order; the T lanes of a game
                 // are in one wave)
