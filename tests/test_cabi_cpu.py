@@ -38,8 +38,9 @@ def test_struct_layout_matches_header():
 
 
 def test_step_k_availability_is_decided_on_the_host():
-    """ewn_step_k: table-driven configurations only; MT19937-compat dice only without auto-reset (its windows are rebuilt
-    between launches); unknown agents are invalid, unsupported ones answer 0."""
+    """ewn_step_k: table-driven configurations, and the generic K-step kernel for the geometries without a table image (RandomAgent /
+    sample agents); MT19937-compat dice only without auto-reset (its windows are rebuilt between launches); unknown agents are
+    invalid, unsupported ones answer 0."""
     lib = _lib.load()
     ok = lambda **kw: lib.ewn_step_k_supported(C.byref(cfg(**kw)), kw.pop("_agent", 0), kw.pop("_depth", 3))  # noqa: E731
     assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=1, rng_kind=1, autoreset=1)), 0, 0) == 1
@@ -52,7 +53,13 @@ def test_step_k_availability_is_decided_on_the_host():
     assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=2, rng_kind=0, autoreset=1)), 0, 0) == 0
     assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=2, rng_kind=1, shaped=1)), 0, 0) == 0
     assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=1, rng_kind=1, shaped=1)), 0, 0) in (0, 1)
-    assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=1, rng_kind=1, board_size=7, cube_layer=4)), 0, 0) == 0
+    # no table image for cube_layer 4 / 5 and 9x9 .. 11x11: the generic K-step kernel, RandomAgent / sample agents only
+    assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=1, rng_kind=1, board_size=7, cube_layer=4)), 0, 0) == 1
+    assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=0, rng_kind=1, board_size=9, cube_layer=3)), 2, 0) == 1
+    assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=1, rng_kind=1, board_size=7, cube_layer=4)), 1, 3) == 0
+    assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=1, rng_kind=0, autoreset=1, board_size=7, cube_layer=5)), 0, 0) == 0
+    assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=1, rng_kind=1, shaped=1, board_size=7, cube_layer=4)), 0, 0) == 0
+    assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=1, rng_kind=1, heuristic=4, board_size=7, cube_layer=4)), 0, 0) == 0   # 'sim_winrate' leaves
     assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=1, rng_kind=1)), 1, 7) == 0
     assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=1, rng_kind=1)), 1, 0) == -1
     assert lib.ewn_step_k_supported(C.byref(cfg(opponent_kind=1, rng_kind=1)), 9, 3) == -1
