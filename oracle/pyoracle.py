@@ -186,7 +186,7 @@ class OracleVecEnv:
             raise AssertionError("bad config")  # envs/ewn.py:47
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None and C is not None:   # (module globals are gone when the interpreter shuts down)
             lib().ewn_oracle_destroy(C.c_void_p(self.h))
             self.h = None
 

@@ -33,7 +33,7 @@ fi
 if [[ $P == *B* ]]; then
   timeout -k 10 300 tools/sweep_rollout.sh $O/sweep_rollout.txt > /dev/null 2>&1; tail -3 $O/sweep_rollout.txt
   timeout -k 10 100 python3 tools/eval_time.py > $O/eval_time.txt 2>&1
-  for p in "" r02 d5 r03; do
+  for p in "" r02 d5 r03 r03b; do
     timeout -k 10 600 python3 tools/soak_parity.py $p > $O/soak_${p:-step}.log 2>&1; echo rc=$? >> $O/soak_${p:-step}.log; tail -2 $O/soak_${p:-step}.log
   done
   timeout -k 10 900 tools/profile_a2c.sh $O/a2c > /dev/null 2>&1; cat $O/a2c/throughput.txt

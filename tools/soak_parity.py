@@ -1,5 +1,5 @@
 """One-off soak: lock-step HIP vs CPU oracle on many lanes and steps (all six outputs bit-exact), beyond what tests/ runs.
-usage (GPU box): python tools/soak_parity.py [mcts | predict | r02 | d5 | long]"""
+usage (GPU box): python tools/soak_parity.py [mcts | predict | r02 | d5 | r03 | r03b | long]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -208,3 +208,42 @@ if len(sys.argv) > 1 and sys.argv[1] == "r03":
     tf.test_fused_gradient_matches_torch_autograd(ea, 65536, 5, 5, 0.0, "minimax")
     tf.test_fused_gradient_matches_torch_autograd(ea, 131072, 5, 7, 0.01, "minimax")
     print("ok fused A2C gradient vs torch autograd at 65 536 x 5 and 131 072 x 7 samples (%.1f s)" % (time.time() - t0), flush=True)
+
+if len(sys.argv) > 1 and sys.argv[1] == "r03b":
+    # second session of round 3: the compile-time trajectory instances at the bench's own shape (record + reward: TRJ = 1, both rollout
+    # kernels; no trajectory at all: TRJ = 2, final state and totals against the oracle), BASELINE config 2 as records, and the generic
+    # K-step kernel (geometries without a table image) beyond the suite's sizes
+    from tests import test_gpu_rollout as tr
+    t0 = time.time()
+    n = tr._rollout_vs_oracle(ea, 65536, 63000, 65048, 50, 4, layout="record", opponent_policy="minimax", max_depth=3, rng="philox", philox_key=2024)
+    print("ok 65 536 lanes, record layout, 4 launches x 50 steps, 2 048-lane slice: %d episodes (%.1f s)" % (n, time.time() - t0), flush=True)
+    n = tr._rollout_vs_oracle(ea, 65536, 0, 4096, 50, 3, layout="record", opponent_policy="random", rng="philox", philox_key=2025)
+    print("ok config 2 (RandomAgent opponent) as records, 3 x 50 steps, 4 096-lane slice: %d episodes (%.1f s)" % (n, time.time() - t0), flush=True)
+    n = tr._rollout_vs_oracle(ea, 16384, 8000, 10048, 40, 3, layout="record", opponent_policy="minimax", max_depth=3, rng="philox", philox_key=2026)
+    print("ok 16 384 lanes (lock-step kernel), record layout: %d episodes (%.1f s)" % (n, time.time() - t0), flush=True)
+    for N, lo, kw in ((65536, 20000, dict(max_depth=3)), (140000, 139000, dict(max_depth=4, heuristic="attk")), (66000, 0, dict(max_depth=3, board_size=7))):
+        S = kw.get("board_size", 5)
+        env = ea.VecEWN(N, opponent_policy="minimax", rng="philox", philox_key=77, autoreset=True, seed_stride=N, **kw)
+        seeds = (np.arange(N, dtype=np.uint64) * 3 + 99).astype(np.uint32)
+        env.reset(seeds=seeds)
+        hi = lo + 1000
+        orc = po.OracleVecEnv(hi - lo, opponent="minimax", rng="philox", philox_key=77, autoreset=True, seed_stride=N, lane_offset=lo, **kw)
+        ob, od = orc.reset(seeds=seeds[lo:hi])
+        tot = env.alloc_totals()
+        ret = np.zeros(hi - lo); nep = np.zeros(hi - lo, np.int64); nwin = np.zeros(hi - lo, np.int64)
+        for launch in range(3):
+            env.rollout(35, totals=tot)                      # no trajectory: the TRJ = 2 instance
+            for k in range(35):
+                ob, od, r, te, trn, info = orc.step(orc.random_actions())
+                ret += r; nep += te != 0; nwin += info == 2
+            assert np.array_equal(env.board[lo:hi].cpu().numpy(), ob) and np.array_equal(env.dice[lo:hi].cpu().numpy(), od), (N, launch)
+        assert np.array_equal(bits(tot["return_sum"][lo:hi].cpu().numpy()), bits(ret))
+        assert np.array_equal(tot["n_episodes"][lo:hi].cpu().numpy(), nep) and np.array_equal(tot["n_wins"][lo:hi].cpu().numpy(), nwin)
+        print("ok no-trajectory rollouts N=%d %s: %d episodes in the slice (%.1f s)" % (N, kw, int(nep.sum()), time.time() - t0), flush=True)
+    n = tr._rollout_vs_oracle(ea, 40000, 30000, 30512, 12, 3, layout="record", board_size=7, cube_layer=4, opponent_policy="minimax", max_depth=3, rng="philox", philox_key=5)
+    print("ok generic K-step kernel 7x7 cube_layer 4 depth 3, 40 000 lanes: %d episodes (%.1f s)" % (n, time.time() - t0), flush=True)
+    n = tr._rollout_vs_oracle(ea, 70000, 69000, 70000, 20, 3, board_size=10, opponent_policy="random", rng="philox", philox_key=6)
+    print("ok generic K-step kernel 10x10 RandomAgent opponent, 70 000 lanes: %d episodes (%.1f s)" % (n, time.time() - t0), flush=True)
+    n = tr._rollout_vs_oracle(ea, 20000, 0, 512, 10, 2, board_size=8, cube_layer=5, opponent_policy="minimax", max_depth=2, heuristic="min_dist", rng="philox", philox_key=7)
+    print("ok generic K-step kernel 8x8 cube_layer 5 depth 2 min_dist: %d episodes (%.1f s)" % (n, time.time() - t0), flush=True)
+    print("r03b soak passed")
