@@ -79,6 +79,8 @@ def parse():
     ap.add_argument("--force-collectives", action="store_true",
                     help="run the N>1 code path (process group, barrier, MAX / ones / digest all-reduces) even at WORLD_SIZE=1: "
                          "exercises the RCCL branch on a one-GPU box")
+    ap.add_argument("--collective-barrier", action="store_true",
+                    help="N > 1: bracket the timed region with dist.barrier() (an RCCL all-reduce) instead of the node-local shared-memory barrier")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra measurements (single-step launch, no-trajectory rollout, uniform6 agent)")
     return ap.parse_args()
 
@@ -154,6 +156,66 @@ def pmc_key(mode, opponent, max_depth, rng, board_size, lanes, steps_per_launch,
         if trajectory and layout != "record":
             key += "_" + layout
     return key
+
+
+class ShmBarrier:
+    """Barrier across the ranks of one node through a shared-memory segment: rank r writes the epoch into slot r and spins until every slot
+    has reached it.  Aligned 8-byte stores; a slot has one writer.  Falls back to dist.barrier() (self.ok False) if the segment cannot be set up."""
+
+    def __init__(self, world, rank, dist):
+        import numpy as np
+        from multiprocessing import shared_memory
+        self.world, self.rank, self.dist, self.epoch, self.ok, self.shm = world, rank, dist, 0, False, None
+        name = "ewn_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "run"))
+        name = "".join(c if c.isalnum() or c == "_" else "_" for c in name)[:60]
+        try:
+            if rank == 0:
+                try:
+                    stale = shared_memory.SharedMemory(name=name)
+                    stale.close(); stale.unlink()
+                except FileNotFoundError:
+                    pass
+                self.shm = shared_memory.SharedMemory(name=name, create=True, size=8 * world)
+                np.ndarray((world,), dtype=np.int64, buffer=self.shm.buf)[:] = 0
+            dist.barrier()                     # the segment exists and is zeroed
+            if rank != 0:
+                self.shm = shared_memory.SharedMemory(name=name)
+                try:   # Python < 3.13 registers an ATTACHED segment with this process's resource tracker too, which then unlinks it a second time at exit
+                    from multiprocessing import resource_tracker
+                    resource_tracker.unregister(self.shm._name, "shared_memory")
+                except Exception:
+                    pass
+            self.slots = np.ndarray((world,), dtype=np.int64, buffer=self.shm.buf)
+            flag = 1
+        except Exception as exc:               # every rank must take the same decision: agree on it below
+            print("note: shared-memory barrier unavailable on rank %d (%r)" % (rank, exc), file=sys.stderr)
+            flag = 0
+        import torch
+        t = torch.tensor([flag], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        self.ok = bool(int(t.item()))
+
+    def wait(self):
+        if not self.ok:
+            self.dist.barrier()
+            return
+        self.epoch += 1
+        e = self.epoch
+        self.slots[self.rank] = e
+        t0 = time.perf_counter()
+        while int(self.slots.min()) < e:
+            if time.perf_counter() - t0 > 120.0:
+                raise RuntimeError("shared-memory barrier timed out (a rank died?)")
+
+    def close(self):
+        try:
+            if self.shm is not None:
+                self.slots = None
+                self.shm.close()
+                if self.rank == 0:
+                    self.shm.unlink()
+        except Exception:
+            pass
 
 
 class HipGraph:
@@ -382,10 +444,22 @@ def main():
         env.reset(seeds=lane_seeds(lo, hi).cuda())  # reference default seed 9487 + global lane id
         return env
 
+    # The barrier that brackets the timed region.  Across ranks of ONE node it is a host-side barrier in shared memory (every rank
+    # publishes an epoch number in its own slot and waits until all slots carry it: ~2 us), taken after the rank's own
+    # torch.cuda.synchronize().  A collective barrier (dist.barrier() on RCCL: a tiny all-reduce kernel plus its wait, measured +17 us
+    # at world_size 1 and more across GPUs) would sit INSIDE a timed region that is 0.17 ms long in the driver's --steps 20 shape and
+    # read as a scaling loss of a path that has no data-path collective at all.  --collective-barrier keeps dist.barrier(); so does
+    # any failure to set the shared segment up, and a job that spans nodes.
+    shm_bar = None
+    if dist_on and world > 1 and not args.collective_barrier and int(os.environ.get("LOCAL_WORLD_SIZE", world)) == world:
+        shm_bar = ShmBarrier(world, rank, dist)
+
     def barrier():
-        if dist_on:
+        if dist_on and shm_bar is None:
             dist.barrier()
         torch.cuda.synchronize()
+        if shm_bar is not None:
+            shm_bar.wait()
 
     env = make_env()
     mode = args.mode
@@ -535,6 +609,8 @@ def main():
                        "opponent": args.opponent, "max_depth": args.max_depth, "rng": args.rng, "mode": mode, "launch": launch,
                        "kernel_launches_in_timed_region": launches,
                        "clock_warmup": None if args.no_spin else "a scratch env of the same configuration stepped in ~1 ms chunks until its step time is stable (>= %g ms, <= 300 ms) right before the timed region (untimed, other state)" % args.spin_ms,
+                       "timing_barrier": (None if not dist_on else ("host-side barrier in node-local shared memory after each rank's own synchronize" if (shm_bar is not None and shm_bar.ok)
+                                                                    else "dist.barrier() (%s) + synchronize" % args.backend)),
                        "parallelism": "lanes sharded across %d GPU(s), no data-path collective" % world},
             "rccl_ranks": ranks_seen if args.backend == "nccl" else None,
             "collective": {"backend": args.backend if dist_on else None, "ranks": ranks_seen},
@@ -545,6 +621,8 @@ def main():
         print(json.dumps(line), flush=True)
     if dist_on:
         dist.barrier()
+        if shm_bar is not None:
+            shm_bar.close()
         dist.destroy_process_group()
 
 

@@ -30,6 +30,7 @@ def test_bench_gpus2_starts_two_ranks_and_shards_are_invariant(prelaunched, suff
     assert two["state_digest"] == one["state_digest"]
     assert two["config"]["mode"] == one["config"]["mode"] == ("step" if suffix else two["config"]["mode"])
     assert two["cpu_baseline"] is None                 # rank 0 at N=1 only
+    assert "shared memory" in two["config"]["timing_barrier"] and one["config"]["timing_barrier"] is None
 
 
 def test_short_bench_line_is_self_consistent(prelaunched):

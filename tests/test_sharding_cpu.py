@@ -69,3 +69,41 @@ def test_two_gloo_ranks_equal_single_process():
     b1, _, wins1, steps1 = _run_shard(0, N_TOTAL, N_TOTAL)
     assert np.array_equal(boards, b1)
     assert counters == [wins1, steps1] and steps1 == N_TOTAL * STEPS
+
+
+def _barrier_worker(rank, world, port, q):
+    """bench.ShmBarrier under two gloo ranks: nobody leaves round i before everybody has entered it"""
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    b = bench.ShmBarrier(world, rank, dist)
+    seen = []
+    for i in range(50):
+        if rank == i % world:
+            time.sleep(0.002)                 # the late rank of this round
+        b.wait()
+        seen.append(int(b.slots.min()))       # after leaving round i + 1: every slot carries at least i + 1
+    ok = b.ok and all(v >= i + 1 for i, v in enumerate(seen))
+    b.close()
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_shared_memory_barrier_two_ranks():
+    """the node-local barrier bench.py brackets its timed region with at N > 1 (instead of an RCCL all-reduce inside a 0.2 ms region)"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_barrier_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
