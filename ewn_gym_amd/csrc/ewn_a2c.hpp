@@ -382,6 +382,47 @@ __global__ __launch_bounds__(256) void k_a2c_reduce(A2cRedBuf B)
         B.grad[i] = ((part[0][e] + part[1][e]) + (part[2][e] + part[3][e])) + ((part[4][e] + part[5][e]) + (part[6][e] + part[7][e]));
 }
 
+// The same sum with 8-byte loads and every load of a thread in flight at once: 16 element PAIRS per block, sixteen threads per pair, each
+// summing every sixteenth block (16 independent loads for the 256 blocks of a full launch), then the sixteen partial sums in a fixed
+// order.  Needs an even P and an 8-byte aligned `partial` (the launcher checks; k_a2c_reduce above is the fallback).  11.2 -> measured
+// in profiles/r03/a2c/kernel_stats.csv.
+#define A2C_RED2_E 16
+__global__ __launch_bounds__(256) void k_a2c_reduce2(A2cRedBuf B)
+{
+    __shared__ float2 part[16][A2C_RED2_E];
+    const int e = (int)threadIdx.x & (A2C_RED2_E - 1), q = (int)threadIdx.x / A2C_RED2_E, i = 2 * ((int)blockIdx.x * A2C_RED2_E + e);
+    float2 s = make_float2(0.0f, 0.0f);
+    if (i < B.P) {
+        const float2 *p = (const float2 *)(B.partial + i);
+        const size_t row = (size_t)(B.P >> 1);
+        float2 v[16];
+        int b = q;
+        for (; b + 240 < B.blocks; b += 256) {
+            #pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = p[(size_t)(b + 16 * u) * row];
+            #pragma unroll
+            for (int u = 0; u < 16; u += 4) {   // a fixed tree: bit-reproducible
+                s.x += (v[u].x + v[u + 1].x) + (v[u + 2].x + v[u + 3].x);
+                s.y += (v[u].y + v[u + 1].y) + (v[u + 2].y + v[u + 3].y);
+            }
+        }
+        for (; b < B.blocks; b += 16) { const float2 w = p[(size_t)b * row]; s.x += w.x; s.y += w.y; }
+    } else if (i < B.P + 8) {
+        for (int b = q; b < B.blocks; b += 16) { s.x += B.stats[(size_t)b * 8 + (i - B.P)]; s.y += B.stats[(size_t)b * 8 + (i - B.P) + 1]; }
+    }
+    part[q][e] = s;
+    __syncthreads();
+    if (q == 0 && i < B.P + 8) {
+        float2 t = make_float2(0.0f, 0.0f);
+        #pragma unroll
+        for (int k = 0; k < 16; k += 4) {
+            t.x += (part[k][e].x + part[k + 1][e].x) + (part[k + 2][e].x + part[k + 3][e].x);
+            t.y += (part[k][e].y + part[k + 1][e].y) + (part[k + 2][e].y + part[k + 3][e].y);
+        }
+        B.grad[i] = t.x; B.grad[i + 1] = t.y;
+    }
+}
+
 // ---- clip_grad_norm_(max_grad_norm) + RMSprop(alpha, eps) step (torch.optim.RMSprop as SB3's A2C configures it: centered = False,
 // momentum 0, weight_decay 0): sq = alpha sq + (1 - alpha) g^2; p -= lr g / (sqrt(sq) + eps).  ONE block (13 k parameters): the norm
 // needs every element, and a second launch would cost more than the arithmetic.

@@ -127,6 +127,13 @@ int64_t ewn_a2c_scratch_bytes(const ewn_config *cfg, int K)
     return ((int64_t)K * k.N + (int64_t)A2C_MAX_BLOCKS * (P + 8) + 64) * 4;
 }
 
+// partials -> flat gradient: the 8-byte-load kernel where the layout allows it
+static void a2c_reduce_launch(const A2cRedBuf &rb, hipStream_t s)
+{
+    if ((rb.P & 1) == 0 && ((uintptr_t)rb.partial & 7) == 0) k_a2c_reduce2<<<(rb.P + 8 + 2 * A2C_RED2_E - 1) / (2 * A2C_RED2_E), 256, 0, s>>>(rb);
+    else k_a2c_reduce<<<(rb.P + 8 + A2C_RED_E - 1) / A2C_RED_E, 256, 0, s>>>(rb);
+}
+
 // 5x5, f32 MFMA: two waves per tile (k_a2c_grad2)
 static int a2c_grad_launch_team(const A2cCfg &ac, A2cBuf ab, float *grad, hipStream_t s)
 {
@@ -140,7 +147,7 @@ static int a2c_grad_launch_team(const A2cCfg &ac, A2cBuf ab, float *grad, hipStr
     kv<<<blocks, 512, lds, s>>>(ac, ab);
     kp<<<blocks, 512, lds, s>>>(ac, ab);
     A2cRedBuf rb = { ab.partial, ab.stats, grad, blocks, MlpGeo<5>::P };
-    k_a2c_reduce<<<(MlpGeo<5>::P + 8 + A2C_RED_E - 1) / A2C_RED_E, 256, 0, s>>>(rb);
+    a2c_reduce_launch(rb, s);
     return launch_status();
 }
 
@@ -158,7 +165,7 @@ static int a2c_grad_launch_b3(const A2cCfg &ac, A2cBuf ab, float *grad, hipStrea
     kv<<<blocks, 256, lds, s>>>(ac, ab);         // value pass first: it leaves the advantages for the policy pass
     kp<<<blocks, 256, lds, s>>>(ac, ab);
     A2cRedBuf rb = { ab.partial, ab.stats, grad, blocks, MlpGeo<S>::P };
-    k_a2c_reduce<<<(MlpGeo<S>::P + 8 + A2C_RED_E - 1) / A2C_RED_E, 256, 0, s>>>(rb);
+    a2c_reduce_launch(rb, s);
     return launch_status();
 }
 
@@ -181,7 +188,7 @@ static int a2c_grad_launch(const A2cCfg &ac, A2cBuf ab, float *grad, hipStream_t
     kv<<<blocks, NWV * 64, lds, s>>>(ac, ab);    // value pass first: it leaves the advantages for the policy pass
     kp<<<blocks, NWV * 64, lds, s>>>(ac, ab);
     A2cRedBuf rb = { ab.partial, ab.stats, grad, blocks, MlpGeo<S>::P };
-    k_a2c_reduce<<<(MlpGeo<S>::P + 8 + A2C_RED_E - 1) / A2C_RED_E, 256, 0, s>>>(rb);
+    a2c_reduce_launch(rb, s);
     return launch_status();
 }
 
