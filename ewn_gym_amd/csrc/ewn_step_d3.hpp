@@ -221,7 +221,11 @@ __device__ __forceinline__ double d5_search(const FastTab<S> *Tb, const RState<S
 // (levels 1, 2 and 3 measure the same; 2 keeps the MT19937 refill waves, which run at 3, in front).
 #define D3_PRIO_HI() __builtin_amdgcn_s_setprio(2)
 #define D3_PRIO_LO() __builtin_amdgcn_s_setprio(0)
+// keeps the stages of a root apart in the ROLLED root loop (without it the register-pressure-driven schedule re-serialises the LDS
+// reads into one round trip per leaf).  The slot-task kernel's three roots are unrolled (PERLANE): there the compiler's own schedule is
+// the better one (measured round 3: 6.53 -> 6.46 us per env step without the fences; without the priority switches 6.74)
 #define D3_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define D3_SEARCH_FENCE() do { if constexpr (!PERLANE) __builtin_amdgcn_sched_barrier(0); } while (0)   // inside d3_search
 #define D3_CUT 0x4000u    // key flag of d3_search: the reply loop stops inside this cube's replies (byte-offset ranks stay below 0x2000)
 
 // element `sub + T * i` of a six-element array held identically by the T lanes of a group, for the lane with index `sub`
@@ -376,7 +380,7 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
                     }
                 }
             }
-            D3_STAGE_FENCE();
+            D3_SEARCH_FENCE();
             #pragma unroll
             for (int ii = 0; ii < CH; ii++) {
                 #pragma unroll
@@ -385,7 +389,7 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
                     a[ii][d] = ft_rank8<S>(Tb, (ft_addr(ix, iy) & keep[i0 + ii][d]) | fixed[i0 + ii][d]);
                 }
             }
-            D3_STAGE_FENCE();
+            D3_SEARCH_FENCE();
             u32 p1[CH], p2[CH];
             double va[CH], v1[CH], v2[CH];
             #pragma unroll
@@ -393,7 +397,7 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
                 p1[ii] = min(a[ii][0], a[ii][1]); p2[ii] = min(p1[ii], a[ii][2]);
                 va[ii] = ft_val<S>(Tb, a[ii][0]); v1[ii] = ft_val<S>(Tb, p1[ii]); v2[ii] = ft_val<S>(Tb, p2[ii]); // +inf for "no such reply"
             }
-            D3_STAGE_FENCE();
+            D3_SEARCH_FENCE();
             D3_PRIO_LO();
             #pragma unroll
             for (int ii = 0; ii < CH; ii++) {
