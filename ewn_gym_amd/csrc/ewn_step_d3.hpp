@@ -398,7 +398,9 @@ __device__ __forceinline__ double d3_search(const FastTab<S> *Tb, const RState<S
                 va[ii] = ft_val<S>(Tb, a[ii][0]); v1[ii] = ft_val<S>(Tb, p1[ii]); v2[ii] = ft_val<S>(Tb, p2[ii]); // +inf for "no such reply"
             }
             D3_SEARCH_FENCE();
-            D3_PRIO_LO();
+            // (the priority stays raised through the cut-off replay and the expectation below, until the search returns: the wave that
+            // shares the SIMD is then mostly in the latency-bound halves of its env step.  Lowering it here, for the arithmetic part of
+            // a root, was round 2's choice; measured round 3 on the final loop: 6.46 -> 6.20 us per env step with the raise kept)
             #pragma unroll
             for (int ii = 0; ii < CH; ii++) {
                 const int i = i0 + ii;
